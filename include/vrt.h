@@ -1,0 +1,141 @@
+/*
+ * vrt.h -- C ABI of the MI355X voxel ray tracer (libvrt.so).
+ *
+ * Drop-in boundary for ONE path of Solvir777/Raytracing: the per-pixel ray
+ * generation + grid traversal + shading that the reference runs as a Vulkan
+ * compute dispatch.  The reference has no FFI for this path; its seam is the
+ * `GraphicsCore` inherent impl (src/graphics/mod.rs).  Each entry point below
+ * names the reference method it replaces.  A Rust (or any other) host binds
+ * these symbols; no C++ or torch types cross the boundary.
+ *
+ * Conventions: every call returns VRT_OK (0) or a negative VRT_E_* code and
+ * never throws or aborts; vrt_last_error() gives a thread-local message.
+ * Inputs are borrowed for the duration of the call; outputs are caller owned.
+ * A context is bound to one HIP device and is not thread-safe.  There is no
+ * CPU fallback: without a usable HIP device vrt_create fails.
+ */
+#ifndef VRT_H
+#define VRT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VRT_OK              0
+#define VRT_E_INVALID_ARG  (-1)
+#define VRT_E_NO_DEVICE    (-2)
+#define VRT_E_OUT_OF_MEMORY (-3)
+#define VRT_E_UNSUPPORTED  (-4)
+#define VRT_E_HIP          (-5)
+#define VRT_E_NO_WORLD     (-6)
+
+/* `GraphicsCore::CHUNK_SIZE` (src/graphics/mod.rs:147). */
+#define VRT_CHUNK_SIZE 32
+
+/* Voxel storage, as uploaded and as held in HBM. */
+#define VRT_VOXEL_REF_U16U16 0u /* two r16ui images: block ids + distance field (src/graphics/mod.rs:354-382) */
+#define VRT_VOXEL_PACKED_U8  1u /* one u8 per voxel, 0 = air; no distance image */
+
+/* Which traversal kernel vrt_trace launches. */
+#define VRT_TRACE_AUTO    0u /* SKIP when the distance image is all zero (as shipped), else LITERAL */
+#define VRT_TRACE_LITERAL 1u /* one voxel per iteration, straight restatement of raytrace.glsl:26-77 */
+#define VRT_TRACE_SKIP    2u /* exact empty-space skipping over 4^3-cell occupancy masks + cell distance field */
+
+#define VRT_MEM_HOST   0u
+#define VRT_MEM_DEVICE 1u
+
+typedef struct vrt_ctx vrt_ctx;
+
+typedef struct vrt_config {
+    uint32_t struct_size;   /* sizeof(vrt_config) */
+    int32_t  device;        /* HIP device ordinal */
+    uint32_t grid_n;        /* voxels per axis of the toroidal window; multiple of 8, 8..4096.
+                               The reference uses 32*(2*render_distance+3) = 160 (src/graphics/mod.rs:359) */
+    uint32_t voxel_format;  /* VRT_VOXEL_* */
+    uint32_t max_steps;     /* per-ray iteration cap; 0 = 4*grid_n.  The reference disables its own
+                               cap (raytrace.glsl:43) and can spin for ever on degenerate rays. */
+    uint32_t trace_mode;    /* VRT_TRACE_* */
+} vrt_config;
+
+/* Per-pixel output planes for rows [y0,y1) of the frame; any pointer may be NULL.
+ * Pixel (row r, column c) is element (r - y0)*w + c of each plane.  Row r is what
+ * the reference stores at image row r: invocation y = h - r (render.comp:13). */
+typedef struct vrt_outputs {
+    uint32_t struct_size;   /* sizeof(vrt_outputs) */
+    uint32_t memory;        /* VRT_MEM_HOST or VRT_MEM_DEVICE: where ALL non-NULL planes live */
+    uint8_t  *bgra8;        /* 4 B/pixel, byte order B,G,R,A = the B8G8R8A8_UNORM swapchain image (src/graphics/mod.rs:77) */
+    int32_t  *voxel;        /* 3 per pixel: hit voxel in world coordinates; on a miss the last anchor */
+    int32_t  *face;         /* 0:-x 1:+x 2:-y 3:+y 4:-z 5:+z = direction of the surface normal; -1 miss; -2 miss by step cap */
+    uint32_t *steps;        /* loop iterations (the shader's panic_counter) */
+    float    *t;            /* t_distances[next_xyz] at the hit; -1 on a miss */
+    float    *hit_point;    /* 3 per pixel; zeros on a miss */
+    float    *rgba;         /* 4 per pixel, the shader's colour before the UNORM store */
+} vrt_outputs;
+
+/* ≙ GraphicsCore::new (src/graphics/mod.rs:292-425), minus window/swapchain:
+ * picks the device, creates the stream, allocates the N^3 world images. */
+int vrt_create(const vrt_config *cfg, vrt_ctx **out);
+int vrt_destroy(vrt_ctx *ctx);
+
+/* Replace the whole world.  `block`: n^3 texels (u16 for REF_U16U16, u8 for PACKED_U8),
+ * linear, x fastest; world voxel p lives at texel rem_euclid(p, n) per axis
+ * (terrain_gen.comp:23).  `dist`: n^3 u16 texels or NULL (all zero); must be NULL for
+ * PACKED_U8.  `memory` says where both pointers live.  The data is copied. */
+int vrt_upload_world(vrt_ctx *ctx, const void *block, const void *dist, uint32_t n, uint32_t memory);
+
+/* ≙ GraphicsCore::upload_chunk_gpu(chunk_pos) (src/graphics/mod.rs:245-291): run the
+ * terrain generator (terrain_gen.comp:14-24, noise.glsl) for the 32^3 voxels of one chunk
+ * and store them at their toroidal texels. */
+int vrt_generate_chunk(vrt_ctx *ctx, int32_t cx, int32_t cy, int32_t cz);
+
+/* The same generator for every world voxel of the cube [wmin, wmin+n)^3 in one launch
+ * (what GameState::upload_chunks_around_player, src/game_logic/game_state.rs:50-83,
+ * achieves chunk by chunk for its 5^3 chunks). */
+int vrt_generate_window(vrt_ctx *ctx, const int32_t wmin[3]);
+
+/* ≙ GraphicsCore::reset_distance_field (src/graphics/mod.rs:150-183): clears the distance
+ * image to zero.  Also the point at which the traversal's own skip structure is rebuilt
+ * after world edits (the reference calls it after every batch of chunk uploads,
+ * game_state.rs:82). */
+int vrt_reset_distance_field(vrt_ctx *ctx);
+
+/* ≙ the compute dispatch inside GraphicsCore::redraw (src/graphics/mod.rs:581-597) with
+ * PushConstants{transform} (src/graphics/push_constants.rs:4-9): trace rows [y0,y1) of a
+ * w x h frame.  `cam_col_major`: the 4x4 f32 transform, column major (nalgebra Matrix4 =
+ * GLSL mat4).  With HOST outputs the call returns when the planes are filled; with DEVICE
+ * outputs it only enqueues work on the context's stream (vrt_sync to wait). */
+int vrt_trace(vrt_ctx *ctx, const float cam_col_major[16], uint32_t w, uint32_t h,
+              uint32_t y0, uint32_t y1, const vrt_outputs *out);
+
+/* Rows of interleaved strips for multi-GPU sharding: strip s (rows [s*strip_h, (s+1)*strip_h))
+ * belongs to part s % parts; traces the strips of `part`, packed in strip order, so plane
+ * element index = (packed_row)*w + c.  vrt_strip_rows gives the packed row count. */
+int vrt_trace_strips(vrt_ctx *ctx, const float cam_col_major[16], uint32_t w, uint32_t h,
+                     uint32_t strip_h, uint32_t part, uint32_t parts, const vrt_outputs *out);
+uint32_t vrt_strip_rows(uint32_t h, uint32_t strip_h, uint32_t part, uint32_t parts);
+
+/* Wait for everything enqueued on the context's stream. */
+int vrt_sync(vrt_ctx *ctx);
+
+/* Copy the block image back (tests of the generator).  `block_out`: n^3 texels. */
+int vrt_download_world(vrt_ctx *ctx, void *block_out, uint32_t memory);
+
+/* HIP-event time of the trace kernel: sum and count over all vrt_trace calls since the
+ * last vrt_kernel_time_reset.  Waits for the stream. */
+int vrt_kernel_time(vrt_ctx *ctx, double *total_ms, uint64_t *launches);
+int vrt_kernel_time_reset(vrt_ctx *ctx);
+/* Name of the kernel the last vrt_trace launched ("literal" or "skip"). */
+const char *vrt_last_kernel_name(vrt_ctx *ctx);
+
+/* The context's hipStream_t, for callers that enqueue their own work behind a trace. */
+void *vrt_stream(vrt_ctx *ctx);
+
+const char *vrt_last_error(void);
+const char *vrt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,380 @@
+// vrt_api.hip -- the extern "C" surface of libvrt.so (include/vrt.h): context, world
+// residency in HBM, kernel selection, HIP-event timing.  No CPU fallback exists: every
+// entry point either runs on the HIP device or returns an error.
+#include "../../include/vrt.h"
+#include "vrt_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(e_ == hipErrorOutOfMemory ? VRT_E_OUT_OF_MEMORY : VRT_E_HIP,        \
+                        "%s failed: %s", #expr, hipGetErrorString(e_));                     \
+    } while (0)
+
+constexpr int kEventRing = 64;
+
+}  // namespace
+
+struct vrt_ctx {
+    int         device       = 0;
+    hipStream_t stream       = nullptr;
+    uint32_t    n            = 0;
+    uint32_t    format       = 0;
+    int         voxel_bytes  = 1;
+    uint32_t    max_steps    = 0;
+    uint32_t    trace_mode   = VRT_TRACE_AUTO;
+    // world in HBM
+    void       *d_block      = nullptr;  // n^3 texels, linear x fastest
+    uint16_t   *d_dist       = nullptr;  // n^3 u16, allocated on first non-null upload
+    bool        dist_nonzero = false;
+    bool        have_world   = false;
+    // skip structure
+    uint64_t   *d_mask       = nullptr;  // (n/4)^3
+    uint8_t    *d_df         = nullptr;  // (n/4)^3
+    uint8_t    *d_df_tmp     = nullptr;
+    bool        skip_valid   = false;
+    uint32_t   *d_flag       = nullptr;
+    // staging for host-resident outputs
+    void       *d_stage      = nullptr;
+    size_t      stage_bytes  = 0;
+    // kernel timing
+    hipEvent_t  ev0[kEventRing], ev1[kEventRing];
+    int         ev_pending   = 0;
+    double      total_ms     = 0.0;
+    uint64_t    launches     = 0;
+    const char *last_kernel  = "none";
+};
+
+namespace {
+
+size_t texels(const vrt_ctx *c) { return (size_t)c->n * c->n * c->n; }
+size_t cells(const vrt_ctx *c) { return texels(c) / 64; }
+
+int drain_events(vrt_ctx *c)
+{
+    for (int i = 0; i < c->ev_pending; ++i) {
+        HIP_TRY(hipEventSynchronize(c->ev1[i]));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev0[i], c->ev1[i]));
+        c->total_ms += ms;
+        c->launches += 1;
+    }
+    c->ev_pending = 0;
+    return VRT_OK;
+}
+
+int ensure_skip_structure(vrt_ctx *c)
+{
+    if (c->skip_valid) return VRT_OK;
+    if (!c->d_mask) {
+        HIP_TRY(hipMalloc(&c->d_mask, cells(c) * sizeof(uint64_t)));
+        HIP_TRY(hipMalloc(&c->d_df, cells(c)));
+        HIP_TRY(hipMalloc(&c->d_df_tmp, cells(c)));
+    }
+    HIP_TRY(vrt::launch_build_masks(c->d_block, c->voxel_bytes, (int)c->n, c->d_mask, c->stream));
+    HIP_TRY(vrt::launch_build_df(c->d_mask, (int)c->n / 4, c->d_df, c->d_df_tmp, c->stream));
+    c->skip_valid = true;
+    return VRT_OK;
+}
+
+struct Plane { size_t off, bytes; void *host; };
+
+int do_trace(vrt_ctx *c, const float *cam, uint32_t w, uint32_t h, const vrt::RowMap &rows, const vrt_outputs *out)
+{
+    if (!c || !cam || !out) return fail(VRT_E_INVALID_ARG, "null argument");
+    if (out->struct_size != sizeof(vrt_outputs)) return fail(VRT_E_INVALID_ARG, "vrt_outputs.struct_size mismatch");
+    if (out->memory != VRT_MEM_HOST && out->memory != VRT_MEM_DEVICE) return fail(VRT_E_INVALID_ARG, "bad outputs.memory");
+    if (w == 0 || h == 0 || w > 16384 || h > 16384) return fail(VRT_E_INVALID_ARG, "frame size out of range");
+    for (int i = 0; i < 16; ++i)
+        if (!std::isfinite(cam[i])) return fail(VRT_E_INVALID_ARG, "camera transform is not finite");
+    for (int i = 12; i < 15; ++i)
+        if (std::fabs(cam[i]) > 1048576.0f) return fail(VRT_E_INVALID_ARG, "camera position beyond +/-2^20");
+    if (!c->have_world) return fail(VRT_E_NO_WORLD, "no world uploaded or generated");
+    HIP_TRY(hipSetDevice(c->device));
+
+    bool use_skip;
+    switch (c->trace_mode) {
+        case VRT_TRACE_LITERAL: use_skip = false; break;
+        case VRT_TRACE_SKIP:
+            if (c->dist_nonzero) return fail(VRT_E_UNSUPPORTED, "skip traversal needs an all-zero distance image");
+            use_skip = true;
+            break;
+        default: use_skip = !c->dist_nonzero; break;
+    }
+    if (use_skip) {
+        int rc = ensure_skip_structure(c);
+        if (rc != VRT_OK) return rc;
+    }
+
+    vrt::TraceParams p;
+    std::memset(&p, 0, sizeof p);
+    std::memcpy(p.m, cam, sizeof p.m);
+    p.w = w; p.h = h; p.rows = rows;
+    p.n = (int)c->n;
+    p.n_pow2_mask = (c->n & (c->n - 1)) == 0 ? (int)c->n - 1 : -1;
+    p.max_steps = c->max_steps;
+    p.block = c->d_block;
+    p.dist = c->dist_nonzero ? c->d_dist : nullptr;
+    p.cell_mask = c->d_mask; p.cell_df = c->d_df; p.nc = (int)c->n / 4;
+
+    const size_t px = (size_t)rows.rows * w;
+    Plane planes[7] = {{0, out->bgra8 ? px * 4 : 0, out->bgra8},       {0, out->voxel ? px * 12 : 0, out->voxel},
+                       {0, out->face ? px * 4 : 0, out->face},         {0, out->steps ? px * 4 : 0, out->steps},
+                       {0, out->t ? px * 4 : 0, out->t},               {0, out->hit_point ? px * 12 : 0, out->hit_point},
+                       {0, out->rgba ? px * 16 : 0, out->rgba}};
+    void *dev[7];
+    if (out->memory == VRT_MEM_DEVICE) {
+        for (int i = 0; i < 7; ++i) dev[i] = planes[i].host;
+    } else {
+        size_t total = 0;
+        for (int i = 0; i < 7; ++i) { planes[i].off = total; total += (planes[i].bytes + 255) & ~(size_t)255; }
+        if (total > c->stage_bytes) {
+            if (c->d_stage) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_stage)); c->d_stage = nullptr; c->stage_bytes = 0; }
+            HIP_TRY(hipMalloc(&c->d_stage, total));
+            c->stage_bytes = total;
+        }
+        for (int i = 0; i < 7; ++i) dev[i] = planes[i].bytes ? (char *)c->d_stage + planes[i].off : nullptr;
+    }
+    p.bgra8 = (uint8_t *)dev[0]; p.voxel = (int32_t *)dev[1]; p.face = (int32_t *)dev[2]; p.steps = (uint32_t *)dev[3];
+    p.t = (float *)dev[4]; p.hit_point = (float *)dev[5]; p.rgba = (float *)dev[6];
+
+    if (c->ev_pending == kEventRing) { int rc = drain_events(c); if (rc != VRT_OK) return rc; }
+    const int e = c->ev_pending;
+    HIP_TRY(hipEventRecord(c->ev0[e], c->stream));
+    if (use_skip) { HIP_TRY(vrt::launch_trace_skip(p, c->voxel_bytes, c->stream)); c->last_kernel = "skip"; }
+    else          { HIP_TRY(vrt::launch_trace_literal(p, c->voxel_bytes, c->stream)); c->last_kernel = "literal"; }
+    HIP_TRY(hipEventRecord(c->ev1[e], c->stream));
+    c->ev_pending = e + 1;
+
+    if (out->memory == VRT_MEM_HOST) {
+        for (int i = 0; i < 7; ++i)
+            if (planes[i].bytes) HIP_TRY(hipMemcpyAsync(planes[i].host, dev[i], planes[i].bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return VRT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *vrt_last_error(void) { return g_err; }
+const char *vrt_version(void) { return "vrt 0.1 (gfx950)"; }
+
+int vrt_create(const vrt_config *cfg, vrt_ctx **out)
+{
+    if (!cfg || !out) return fail(VRT_E_INVALID_ARG, "null argument");
+    *out = nullptr;
+    if (cfg->struct_size != sizeof(vrt_config)) return fail(VRT_E_INVALID_ARG, "vrt_config.struct_size mismatch");
+    if (cfg->grid_n < 8 || cfg->grid_n > 4096 || cfg->grid_n % 8 != 0)
+        return fail(VRT_E_INVALID_ARG, "grid_n must be a multiple of 8 in [8, 4096]");
+    if (cfg->voxel_format != VRT_VOXEL_REF_U16U16 && cfg->voxel_format != VRT_VOXEL_PACKED_U8)
+        return fail(VRT_E_INVALID_ARG, "unknown voxel_format");
+    if (cfg->trace_mode > VRT_TRACE_SKIP) return fail(VRT_E_INVALID_ARG, "unknown trace_mode");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(VRT_E_NO_DEVICE, "no HIP device available");
+    if (cfg->device < 0 || cfg->device >= count) return fail(VRT_E_NO_DEVICE, "device %d out of range (%d devices)", cfg->device, count);
+    HIP_TRY(hipSetDevice(cfg->device));
+
+    vrt_ctx *c = new (std::nothrow) vrt_ctx();
+    if (!c) return fail(VRT_E_OUT_OF_MEMORY, "host allocation failed");
+    c->device      = cfg->device;
+    c->n           = cfg->grid_n;
+    c->format      = cfg->voxel_format;
+    c->voxel_bytes = cfg->voxel_format == VRT_VOXEL_PACKED_U8 ? 1 : 2;
+    c->max_steps   = cfg->max_steps ? cfg->max_steps : 4 * cfg->grid_n;
+    c->trace_mode  = cfg->trace_mode;
+    for (int i = 0; i < kEventRing; ++i) { c->ev0[i] = nullptr; c->ev1[i] = nullptr; }
+    auto bail = [&](int code) { vrt_destroy(c); return code; };
+#define TRY_OR_BAIL(expr)                                                                                     \
+    do {                                                                                                      \
+        hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess)                                                                                 \
+            return bail(fail(e_ == hipErrorOutOfMemory ? VRT_E_OUT_OF_MEMORY : VRT_E_HIP, "%s failed: %s",    \
+                             #expr, hipGetErrorString(e_)));                                                  \
+    } while (0)
+    TRY_OR_BAIL(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (int i = 0; i < kEventRing; ++i) { TRY_OR_BAIL(hipEventCreate(&c->ev0[i])); TRY_OR_BAIL(hipEventCreate(&c->ev1[i])); }
+    TRY_OR_BAIL(hipMalloc(&c->d_block, texels(c) * (size_t)c->voxel_bytes));
+    TRY_OR_BAIL(hipMalloc(&c->d_flag, sizeof(uint32_t)));
+#undef TRY_OR_BAIL
+    *out = c;
+    return VRT_OK;
+}
+
+int vrt_destroy(vrt_ctx *c)
+{
+    if (!c) return VRT_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (int i = 0; i < kEventRing; ++i) {
+        if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]);
+        if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]);
+    }
+    void *bufs[] = {c->d_block, c->d_dist, c->d_mask, c->d_df, c->d_df_tmp, c->d_flag, c->d_stage};
+    for (void *b : bufs) if (b) (void)hipFree(b);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return VRT_OK;
+}
+
+int vrt_upload_world(vrt_ctx *c, const void *block, const void *dist, uint32_t n, uint32_t memory)
+{
+    if (!c || !block) return fail(VRT_E_INVALID_ARG, "null argument");
+    if (n != c->n) return fail(VRT_E_INVALID_ARG, "n = %u does not match the context's grid_n = %u", n, c->n);
+    if (memory != VRT_MEM_HOST && memory != VRT_MEM_DEVICE) return fail(VRT_E_INVALID_ARG, "bad memory kind");
+    if (dist && c->format == VRT_VOXEL_PACKED_U8) return fail(VRT_E_INVALID_ARG, "PACKED_U8 has no distance image");
+    HIP_TRY(hipSetDevice(c->device));
+    const hipMemcpyKind kind = memory == VRT_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    HIP_TRY(hipMemcpyAsync(c->d_block, block, texels(c) * (size_t)c->voxel_bytes, kind, c->stream));
+    c->dist_nonzero = false;
+    if (dist) {
+        if (!c->d_dist) HIP_TRY(hipMalloc(&c->d_dist, texels(c) * sizeof(uint16_t)));
+        HIP_TRY(hipMemcpyAsync(c->d_dist, dist, texels(c) * sizeof(uint16_t), kind, c->stream));
+        HIP_TRY(vrt::launch_any_nonzero_u16(c->d_dist, texels(c), c->d_flag, c->stream));
+        uint32_t flag = 0;
+        HIP_TRY(hipMemcpyAsync(&flag, c->d_flag, sizeof flag, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->dist_nonzero = flag != 0;
+    } else {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    c->have_world = true;
+    c->skip_valid = false;
+    return VRT_OK;
+}
+
+int vrt_generate_chunk(vrt_ctx *c, int32_t cx, int32_t cy, int32_t cz)
+{
+    if (!c) return fail(VRT_E_INVALID_ARG, "null argument");
+    if (c->n < VRT_CHUNK_SIZE) return fail(VRT_E_UNSUPPORTED, "grid_n smaller than one chunk");
+    const int32_t lim = (1 << 20) / VRT_CHUNK_SIZE;
+    if (cx < -lim || cx > lim || cy < -lim || cy > lim || cz < -lim || cz > lim)
+        return fail(VRT_E_INVALID_ARG, "chunk position beyond +/-2^20 voxels");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(vrt::launch_terrain(c->d_block, c->voxel_bytes, (int)c->n, cx * VRT_CHUNK_SIZE, cy * VRT_CHUNK_SIZE,
+                                cz * VRT_CHUNK_SIZE, VRT_CHUNK_SIZE, VRT_CHUNK_SIZE, VRT_CHUNK_SIZE, c->stream));
+    c->have_world = true;
+    c->skip_valid = false;
+    return VRT_OK;
+}
+
+int vrt_generate_window(vrt_ctx *c, const int32_t wmin[3])
+{
+    if (!c || !wmin) return fail(VRT_E_INVALID_ARG, "null argument");
+    for (int k = 0; k < 3; ++k)
+        if (wmin[k] < -(1 << 21) || wmin[k] > (1 << 21)) return fail(VRT_E_INVALID_ARG, "window origin beyond +/-2^21");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(vrt::launch_terrain(c->d_block, c->voxel_bytes, (int)c->n, wmin[0], wmin[1], wmin[2], (int)c->n, (int)c->n,
+                                (int)c->n, c->stream));
+    c->have_world = true;
+    c->skip_valid = false;
+    return VRT_OK;
+}
+
+int vrt_reset_distance_field(vrt_ctx *c)
+{
+    if (!c) return fail(VRT_E_INVALID_ARG, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->d_dist) HIP_TRY(hipMemsetAsync(c->d_dist, 0, texels(c) * sizeof(uint16_t), c->stream));
+    c->dist_nonzero = false;
+    if (c->have_world && c->trace_mode != VRT_TRACE_LITERAL) {
+        c->skip_valid = false;
+        return ensure_skip_structure(c);
+    }
+    return VRT_OK;
+}
+
+int vrt_trace(vrt_ctx *c, const float cam[16], uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, const vrt_outputs *out)
+{
+    if (y0 > y1 || y1 > h) return fail(VRT_E_INVALID_ARG, "row band [%u,%u) outside the frame", y0, y1);
+    vrt::RowMap rows{y0, y1 - y0, 0, 0, 1};
+    return do_trace(c, cam, w, h, rows, out);
+}
+
+uint32_t vrt_strip_rows(uint32_t h, uint32_t strip_h, uint32_t part, uint32_t parts)
+{
+    if (strip_h == 0 || parts == 0 || part >= parts) return 0;
+    uint32_t rows = 0;
+    for (uint32_t s = part; (uint64_t)s * strip_h < h; s += parts) {
+        const uint32_t a = s * strip_h, b = a + strip_h < h ? a + strip_h : h;
+        rows += b - a;
+    }
+    return rows;
+}
+
+int vrt_trace_strips(vrt_ctx *c, const float cam[16], uint32_t w, uint32_t h, uint32_t strip_h, uint32_t part,
+                     uint32_t parts, const vrt_outputs *out)
+{
+    if (strip_h == 0 || parts == 0 || part >= parts) return fail(VRT_E_INVALID_ARG, "bad strip partition");
+    if (h % strip_h != 0) return fail(VRT_E_INVALID_ARG, "frame height must be a multiple of strip_h");
+    vrt::RowMap rows{0, vrt_strip_rows(h, strip_h, part, parts), strip_h, part, parts};
+    return do_trace(c, cam, w, h, rows, out);
+}
+
+int vrt_sync(vrt_ctx *c)
+{
+    if (!c) return fail(VRT_E_INVALID_ARG, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return VRT_OK;
+}
+
+int vrt_download_world(vrt_ctx *c, void *block_out, uint32_t memory)
+{
+    if (!c || !block_out) return fail(VRT_E_INVALID_ARG, "null argument");
+    if (!c->have_world) return fail(VRT_E_NO_WORLD, "no world uploaded or generated");
+    HIP_TRY(hipSetDevice(c->device));
+    const hipMemcpyKind kind = memory == VRT_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    HIP_TRY(hipMemcpyAsync(block_out, c->d_block, texels(c) * (size_t)c->voxel_bytes, kind, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return VRT_OK;
+}
+
+int vrt_kernel_time(vrt_ctx *c, double *total_ms, uint64_t *launches)
+{
+    if (!c) return fail(VRT_E_INVALID_ARG, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = drain_events(c);
+    if (rc != VRT_OK) return rc;
+    if (total_ms) *total_ms = c->total_ms;
+    if (launches) *launches = c->launches;
+    return VRT_OK;
+}
+
+int vrt_kernel_time_reset(vrt_ctx *c)
+{
+    if (!c) return fail(VRT_E_INVALID_ARG, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = drain_events(c);
+    c->total_ms = 0.0;
+    c->launches = 0;
+    return rc;
+}
+
+const char *vrt_last_kernel_name(vrt_ctx *c) { return c ? c->last_kernel : "none"; }
+void *vrt_stream(vrt_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+}  // extern "C"

@@ -1,0 +1,55 @@
+// vrt_kernels.h -- host-side launchers of the HIP kernels and the parameter blocks
+// they take.  Internal to libvrt.so (the public surface is include/vrt.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vrt {
+
+// Which rows a launch covers.  Packed row q of the output planes maps to image row
+//   row(q) = y0 + q                                   (strip_h == 0: plain band)
+//   row(q) = ((q / strip_h) * parts + part) * strip_h + q % strip_h   (interleaved strips)
+struct RowMap {
+    uint32_t y0;
+    uint32_t rows;     // packed rows in this launch
+    uint32_t strip_h;  // 0 = plain band
+    uint32_t part, parts;
+};
+
+struct TraceParams {
+    float    m[16];        // camera transform, column major
+    uint32_t w, h;         // frame size
+    RowMap   rows;
+    int32_t  n;            // voxels per axis
+    int32_t  n_pow2_mask;  // n-1 if n is a power of two, else -1
+    uint32_t max_steps;
+    // world
+    const void     *block;  // n^3 texels (u8 or u16), linear x fastest
+    const uint16_t *dist;   // n^3 texels or nullptr (all zero)
+    // skip structure (cells of 4^3 voxels, torus space)
+    const uint64_t *cell_mask;  // (n/4)^3 occupancy masks, bit = (z&3)*16 + (y&3)*4 + (x&3)
+    const uint8_t  *cell_df;    // (n/4)^3 Chebyshev distance (in cells) to the nearest non-empty cell, 0 = non-empty
+    int32_t  nc;                // n / 4
+    // outputs (device pointers, any may be null)
+    uint8_t  *bgra8;
+    int32_t  *voxel;
+    int32_t  *face;
+    uint32_t *steps;
+    float    *t;
+    float    *hit_point;
+    float    *rgba;
+};
+
+// traversal kernels
+hipError_t launch_trace_literal(const TraceParams &p, int voxel_bytes, hipStream_t s);
+hipError_t launch_trace_skip(const TraceParams &p, int voxel_bytes, hipStream_t s);
+
+// world kernels
+hipError_t launch_terrain(void *block, int voxel_bytes, int n, int x0, int y0, int z0,
+                          int ex, int ey, int ez, hipStream_t s);
+hipError_t launch_build_masks(const void *block, int voxel_bytes, int n, uint64_t *cell_mask, hipStream_t s);
+hipError_t launch_build_df(const uint64_t *cell_mask, int nc, uint8_t *df_a, uint8_t *df_b, hipStream_t s);
+hipError_t launch_any_nonzero_u16(const uint16_t *p, size_t count, uint32_t *flag, hipStream_t s);
+
+}  // namespace vrt

@@ -1,0 +1,230 @@
+// vrt_world.hip -- kernels that produce and index the voxel world in HBM.
+//
+//   k_terrain       : terrain_gen.comp:14-24 + noise.glsl:4-74 for a box of world voxels,
+//                     stored at their toroidal texels (bit-exact restatement: same
+//                     operation order as the shader, no FMA contraction).
+//   k_build_masks   : one 64-bit occupancy mask per 4^3 cell of the texel image.
+//   k_df_pass       : one axis of the separable (min, max) Chebyshev distance transform
+//                     over cells (torus metric): out(c) = min_r max(r, in(c +/- r)).
+//                     Three passes (x, y, z) from in = {0 non-empty, 255 empty} give the
+//                     distance, in cells, to the nearest non-empty cell, capped at 255.
+//   k_any_nonzero   : is the uploaded distance image all zero (as shipped)?
+#include "vrt_device.h"
+#include "vrt_kernels.h"
+
+namespace vrt {
+
+// ---------------------------------------------------------------------------
+// noise.glsl
+// ---------------------------------------------------------------------------
+VRT_DEV float glsl_mod(float x, float y) { return x - y * floorf(x / y); }
+VRT_DEV float permute1(float x) { return glsl_mod(((x * 34.0f) + 1.0f) * x, 289.0f); }       // noise.glsl:4
+VRT_DEV float taylor_inv_sqrt(float r) { return 1.79284291400159f - 0.85373472095314f * r; }  // noise.glsl:5
+VRT_DEV float stepf(float edge, float x) { return x < edge ? 0.0f : 1.0f; }
+VRT_DEV float dot3(float ax, float ay, float az, float bx, float by, float bz) { return (ax * bx + ay * by) + az * bz; }
+
+// noise.glsl:7-74
+VRT_DEV float snoise(float vx, float vy, float vz)
+{
+    const float Cx = (float)(1.0 / 6.0), Cy = (float)(1.0 / 3.0);
+    // :12-13
+    const float s  = (vx * Cy + vy * Cy) + vz * Cy;
+    float ix = floorf(vx + s), iy = floorf(vy + s), iz = floorf(vz + s);
+    const float u  = (ix * Cx + iy * Cx) + iz * Cx;
+    const float x0x = (vx - ix) + u, x0y = (vy - iy) + u, x0z = (vz - iz) + u;
+    // :16-19  g = step(x0.yzx, x0.xyz); l = 1 - g; i1 = min(g, l.zxy); i2 = max(g, l.zxy)
+    const float gx = stepf(x0y, x0x), gy = stepf(x0z, x0y), gz = stepf(x0x, x0z);
+    const float lx = 1.0f - gx, ly = 1.0f - gy, lz = 1.0f - gz;
+    const float i1x = fminf(gx, lz), i1y = fminf(gy, lx), i1z = fminf(gz, ly);
+    const float i2x = fmaxf(gx, lz), i2y = fmaxf(gy, lx), i2z = fmaxf(gz, ly);
+    // :22-24
+    const float x1x = (x0x - i1x) + 1.0f * Cx, x1y = (x0y - i1y) + 1.0f * Cx, x1z = (x0z - i1z) + 1.0f * Cx;
+    const float x2x = (x0x - i2x) + 2.0f * Cx, x2y = (x0y - i2y) + 2.0f * Cx, x2z = (x0z - i2z) + 2.0f * Cx;
+    const float x3x = (x0x - 1.0f) + 3.0f * Cx, x3y = (x0y - 1.0f) + 3.0f * Cx, x3z = (x0z - 1.0f) + 3.0f * Cx;
+    // :27-31
+    ix = glsl_mod(ix, 289.0f); iy = glsl_mod(iy, 289.0f); iz = glsl_mod(iz, 289.0f);
+    const float oz[4] = {0.0f, i1z, i2z, 1.0f};
+    const float oy[4] = {0.0f, i1y, i2y, 1.0f};
+    const float ox[4] = {0.0f, i1x, i2x, 1.0f};
+    // :35-36
+    const float n_  = (float)(1.0 / 7.0);
+    const float nsx = n_ * 2.0f - 0.0f, nsy = n_ * 0.5f - 1.0f, nsz = n_ * 1.0f - 0.0f;
+    float x[4], y[4], h[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float a = permute1(iz + oz[c]);
+        const float b = permute1((a + iy) + oy[c]);
+        const float p = permute1((b + ix) + ox[c]);
+        const float j  = p - 49.0f * floorf(p * nsz * nsz);  // :38
+        const float x_ = floorf(j * nsz);                    // :40
+        const float y_ = floorf(j - 7.0f * x_);              // :41
+        x[c] = x_ * nsx + nsy;                               // :43
+        y[c] = y_ * nsx + nsy;                               // :44
+        h[c] = (1.0f - fabsf(x[c])) - fabsf(y[c]);           // :45
+    }
+    // :47-55
+    const float b0[4] = {x[0], x[1], y[0], y[1]};
+    const float b1[4] = {x[2], x[3], y[2], y[3]};
+    float s0[4], s1[4], sh[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        s0[c] = floorf(b0[c]) * 2.0f + 1.0f;
+        s1[c] = floorf(b1[c]) * 2.0f + 1.0f;
+        sh[c] = -stepf(h[c], 0.0f);
+    }
+    const float a0x = b0[0] + s0[0] * sh[0], a0y = b0[2] + s0[2] * sh[0], a0z = b0[1] + s0[1] * sh[1], a0w = b0[3] + s0[3] * sh[1];
+    const float a1x = b1[0] + s1[0] * sh[2], a1y = b1[2] + s1[2] * sh[2], a1z = b1[1] + s1[1] * sh[3], a1w = b1[3] + s1[3] * sh[3];
+    // :57-67
+    float p0x = a0x, p0y = a0y, p0z = h[0];
+    float p1x = a0z, p1y = a0w, p1z = h[1];
+    float p2x = a1x, p2y = a1y, p2z = h[2];
+    float p3x = a1z, p3y = a1w, p3z = h[3];
+    const float n0 = taylor_inv_sqrt(dot3(p0x, p0y, p0z, p0x, p0y, p0z));
+    const float n1 = taylor_inv_sqrt(dot3(p1x, p1y, p1z, p1x, p1y, p1z));
+    const float n2 = taylor_inv_sqrt(dot3(p2x, p2y, p2z, p2x, p2y, p2z));
+    const float n3 = taylor_inv_sqrt(dot3(p3x, p3y, p3z, p3x, p3y, p3z));
+    p0x *= n0; p0y *= n0; p0z *= n0;
+    p1x *= n1; p1y *= n1; p1z *= n1;
+    p2x *= n2; p2y *= n2; p2z *= n2;
+    p3x *= n3; p3y *= n3; p3z *= n3;
+    // :70-73
+    float m0 = fmaxf(0.6f - dot3(x0x, x0y, x0z, x0x, x0y, x0z), 0.0f);
+    float m1 = fmaxf(0.6f - dot3(x1x, x1y, x1z, x1x, x1y, x1z), 0.0f);
+    float m2 = fmaxf(0.6f - dot3(x2x, x2y, x2z, x2x, x2y, x2z), 0.0f);
+    float m3 = fmaxf(0.6f - dot3(x3x, x3y, x3z, x3x, x3y, x3z), 0.0f);
+    m0 = m0 * m0; m1 = m1 * m1; m2 = m2 * m2; m3 = m3 * m3;
+    const float d0 = dot3(p0x, p0y, p0z, x0x, x0y, x0z), d1 = dot3(p1x, p1y, p1z, x1x, x1y, x1z);
+    const float d2 = dot3(p2x, p2y, p2z, x2x, x2y, x2z), d3 = dot3(p3x, p3y, p3z, x3x, x3y, x3z);
+    const float acc = (((m0 * m0) * d0 + (m1 * m1) * d1) + (m2 * m2) * d2) + (m3 * m3) * d3;
+    return 42.0f * acc;
+}
+
+// terrain_gen.comp:14-24 for world voxels [x0,x0+ex) x [y0,y0+ey) x [z0,z0+ez)
+template <typename T>
+__global__ __launch_bounds__(256) void k_terrain(T *block, int n, int x0, int y0, int z0, int ex, int ey, int ez)
+{
+    const int lx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ly = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int lz = blockIdx.z;
+    if (lx >= ex || ly >= ey || lz >= ez) return;
+    const int px = x0 + lx, py = y0 + ly, pz = z0 + lz;
+    const float noise_val = snoise((float)px * 0.015f, (float)py * 0.015f, (float)pz * 0.015f) * 6.0f - (float)py;
+    const T v = noise_val > 0.0f ? (T)1 : (T)0;
+    const size_t tx = (size_t)rem_euclid(px, n), ty = (size_t)rem_euclid(py, n), tz = (size_t)rem_euclid(pz, n);
+    block[(tz * (size_t)n + ty) * (size_t)n + tx] = v;
+}
+
+hipError_t launch_terrain(void *block, int voxel_bytes, int n, int x0, int y0, int z0, int ex, int ey, int ez,
+                          hipStream_t s)
+{
+    if (ex <= 0 || ey <= 0 || ez <= 0) return hipSuccess;
+    // grid.z is limited to 65535; ez <= 4096 here.
+    const dim3 grid((ex + 63) / 64, (ey + 3) / 4, ez), blockdim(256);
+    if (voxel_bytes == 1) k_terrain<uint8_t><<<grid, blockdim, 0, s>>>((uint8_t *)block, n, x0, y0, z0, ex, ey, ez);
+    else k_terrain<uint16_t><<<grid, blockdim, 0, s>>>((uint16_t *)block, n, x0, y0, z0, ex, ey, ez);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// occupancy masks: cell (cx,cy,cz) covers texels [4c, 4c+4)^3, bit = z*16 + y*4 + x
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_build_masks(const T *block, int n, int nc, uint64_t *cell_mask)
+{
+    const int cx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int cy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int cz = blockIdx.z;
+    if (cx >= nc || cy >= nc) return;
+    uint64_t m = 0;
+#pragma unroll
+    for (int z = 0; z < 4; ++z) {
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            const size_t base = ((size_t)(4 * cz + z) * (size_t)n + (size_t)(4 * cy + y)) * (size_t)n + (size_t)(4 * cx);
+            unsigned bits = 0;
+            if (sizeof(T) == 1) {
+                const uint32_t v = *reinterpret_cast<const uint32_t *>(block + base);
+                bits = ((v & 0xffu) ? 1u : 0u) | ((v & 0xff00u) ? 2u : 0u) | ((v & 0xff0000u) ? 4u : 0u) | ((v & 0xff000000u) ? 8u : 0u);
+            } else {
+                const uint2 v = *reinterpret_cast<const uint2 *>(block + base);
+                bits = ((v.x & 0xffffu) ? 1u : 0u) | ((v.x >> 16) ? 2u : 0u) | ((v.y & 0xffffu) ? 4u : 0u) | ((v.y >> 16) ? 8u : 0u);
+            }
+            m |= (uint64_t)bits << (z * 16 + y * 4);
+        }
+    }
+    cell_mask[((size_t)cz * nc + cy) * nc + cx] = m;
+}
+
+hipError_t launch_build_masks(const void *block, int voxel_bytes, int n, uint64_t *cell_mask, hipStream_t s)
+{
+    const int  nc = n / 4;
+    const dim3 grid((nc + 63) / 64, (nc + 3) / 4, nc), blockdim(256);
+    if (voxel_bytes == 1) k_build_masks<uint8_t><<<grid, blockdim, 0, s>>>((const uint8_t *)block, n, nc, cell_mask);
+    else k_build_masks<uint16_t><<<grid, blockdim, 0, s>>>((const uint16_t *)block, n, nc, cell_mask);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// cell distance field
+// ---------------------------------------------------------------------------
+// FROM_MASK: in(c) = mask[c] != 0 ? 0 : 255, else in = previous pass.
+template <bool FROM_MASK>
+__global__ __launch_bounds__(256) void k_df_pass(const uint64_t *cell_mask, const uint8_t *in, uint8_t *out, int nc, int axis)
+{
+    const int cx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int cy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int cz = blockIdx.z;
+    if (cx >= nc || cy >= nc) return;
+    const size_t self = ((size_t)cz * nc + cy) * nc + cx;
+    auto value = [&](size_t i) -> int {
+        if (FROM_MASK) return cell_mask[i] != 0 ? 0 : 255;
+        return (int)in[i];
+    };
+    const int    pos    = axis == 0 ? cx : (axis == 1 ? cy : cz);
+    const size_t stride = axis == 0 ? 1 : (axis == 1 ? (size_t)nc : (size_t)nc * nc);
+    const size_t line   = self - (size_t)pos * stride;
+    int best = value(self);
+    // out = min over r of max(r, in(pos +/- r)); once r >= best nothing can improve
+    for (int r = 1; r < best; ++r) {
+        int p0 = pos - r; p0 += p0 < 0 ? nc : 0; p0 += p0 < 0 ? nc : 0;
+        int p1 = pos + r; p1 -= p1 >= nc ? nc : 0; p1 -= p1 >= nc ? nc : 0;
+        if (r >= nc) {  // more than one lap: every cell of the line has been seen
+            break;
+        }
+        const int v = min(value(line + (size_t)p0 * stride), value(line + (size_t)p1 * stride));
+        best = min(best, max(r, v));
+    }
+    out[self] = (uint8_t)best;
+}
+
+hipError_t launch_build_df(const uint64_t *cell_mask, int nc, uint8_t *df_a, uint8_t *df_b, hipStream_t s)
+{
+    // x pass: mask -> b ; y pass: b -> a ; z pass: a -> b ; result must end in df_a, so
+    // run x: mask -> a, y: a -> b, z: b -> a.
+    const dim3 grid((nc + 63) / 64, (nc + 3) / 4, nc), blockdim(256);
+    k_df_pass<true><<<grid, blockdim, 0, s>>>(cell_mask, nullptr, df_a, nc, 0);
+    k_df_pass<false><<<grid, blockdim, 0, s>>>(nullptr, df_a, df_b, nc, 1);
+    k_df_pass<false><<<grid, blockdim, 0, s>>>(nullptr, df_b, df_a, nc, 2);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_any_nonzero(const uint16_t *p, size_t count, uint32_t *flag)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    unsigned any = 0;
+    for (; i < count; i += stride) any |= p[i];
+    if (__any(any != 0) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+
+hipError_t launch_any_nonzero_u16(const uint16_t *p, size_t count, uint32_t *flag, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(flag, 0, sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    const unsigned blocks = (unsigned)((count + 255) / 256 < 4096 ? (count + 255) / 256 : 4096);
+    k_any_nonzero<<<blocks ? blocks : 1, 256, 0, s>>>(p, count, flag);
+    return hipGetLastError();
+}
+
+}  // namespace vrt

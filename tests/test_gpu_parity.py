@@ -1,0 +1,221 @@
+"""GPU parity: the HIP kernels, called through the C ABI, against the CPU oracle on the
+same inputs.  Bar: bit-exact for every output plane -- integer planes (voxel, face,
+steps, bgra8) and, because both sides evaluate the same canonical binary32 expression
+order without FMA contraction, the float planes (t, hit_point, rgba) too (tolerance 0 ulp,
+compared as bit patterns).
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from raytracing_amd import (GraphicsCore, Player, TRACE_LITERAL, TRACE_SKIP, VOXEL_PACKED_U8,
+                            VOXEL_REF_U16U16, VrtError, scenes)
+
+pytestmark = pytest.mark.gpu
+
+PLANES = ("bgra8", "voxel", "face", "steps", "t", "hit_point", "rgba")
+
+
+def assert_planes_equal(got, want, ctx=""):
+    for k in PLANES:
+        if k not in got or k not in want:
+            continue
+        a, b = got[k], want[k]
+        assert a.shape == b.shape, (ctx, k, a.shape, b.shape)
+        if a.dtype == np.float32:
+            a, b = a.view(np.uint32), b.view(np.uint32)
+        if not np.array_equal(a, b):
+            bad = np.argwhere(a != b)
+            first = tuple(bad[0])
+            raise AssertionError(f"{ctx}: plane {k}: {len(bad)} mismatches, first at {first}: "
+                                 f"gpu={got[k][first]} oracle={want[k][first]}")
+
+
+def core_for(block, mode, dist=None, max_steps=0):
+    fmt = VOXEL_PACKED_U8 if block.dtype == np.uint8 else VOXEL_REF_U16U16
+    g = GraphicsCore(grid_n=block.shape[0], voxel_format=fmt, trace_mode=mode, max_steps=max_steps)
+    g.upload_world(block, dist)
+    return g
+
+
+MODES = [pytest.param(TRACE_LITERAL, id="literal"), pytest.param(TRACE_SKIP, id="skip")]
+
+
+@pytest.fixture(scope="module")
+def scene160():
+    p = scenes.pose_b()
+    return O.terrain_fill(160, scenes.window_min(p.get_position(), 160), np.uint16)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_config1_default_scene_pose_b(scene160, mode):
+    p = scenes.pose_b()
+    cam = scenes.cam16(p)
+    want = O.trace(O.World(scene160), cam, 640, 480)
+    with core_for(scene160, mode) as g:
+        got = g.trace(cam, 640, 480)
+        assert g.last_kernel_name() == ("literal" if mode == TRACE_LITERAL else "skip")
+    assert_planes_equal(got, want, "config1 pose B")
+    assert (want["face"] >= 0).mean() > 0.3  # the scene is in view
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_config1_spawn_pose_is_degenerate_and_capped(mode):
+    # identity transform at the origin: the column x = W/2 has rd.x == 0 and spins until the cap
+    p = scenes.pose_spawn()
+    block = O.terrain_fill(160, scenes.window_min(p.get_position(), 160), np.uint16)
+    cam = scenes.cam16(p)
+    want = O.trace(O.World(block), cam, 640, 480)
+    assert (want["face"] == -2).any()
+    with core_for(block, mode) as g:
+        got = g.trace(cam, 640, 480)
+    assert_planes_equal(got, want, "config1 spawn pose")
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_config2_1080p_over_256(mode):
+    p = scenes.pose_b()
+    block = O.terrain_fill(256, scenes.window_min(p.get_position(), 256), np.uint16)
+    cam = scenes.cam16(p)
+    want = O.trace(O.World(block), cam, 1920, 1080)
+    with core_for(block, mode) as g:
+        got = g.trace(cam, 1920, 1080)
+    assert_planes_equal(got, want, "config2")
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("seed,n,dtype,density", [(0, 32, np.uint16, 0.02), (1, 64, np.uint8, 0.003),
+                                                  (2, 40, np.uint16, 0.0005), (3, 128, np.uint8, 0.0001),
+                                                  (4, 96, np.uint8, 0.3), (5, 8, np.uint8, 0.1), (6, 16, np.uint16, 0.1)])
+def test_random_sparse_grids_and_poses(mode, seed, n, dtype, density):
+    rng = np.random.default_rng(seed)
+    block = ((rng.random((n, n, n)) < density) * rng.integers(1, 250, (n, n, n))).astype(dtype)
+    world = O.World(block)
+    with core_for(block, mode) as g:
+        for i in range(6):
+            pos = rng.uniform(-70, 70, 3)
+            if i % 3 == 0:
+                pos = np.round(pos)  # integer coordinates: exact plane hits, 0*inf cases with yaw 0
+            yaw, pitch = (0.0, 0.0) if i == 0 else (rng.uniform(-3.2, 3.2), rng.uniform(-1.6, 1.6))
+            cam = scenes.cam16(Player.at(pos, yaw, pitch))
+            want = O.trace(world, cam, 96, 64)
+            got = g.trace(cam, 96, 64)
+            assert_planes_equal(got, want, f"seed {seed} pose {i}")
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_empty_and_full_worlds(mode):
+    cam = scenes.cam16(scenes.pose_b())
+    for fill in (0, 9):
+        block = np.full((64, 64, 64), fill, np.uint8)
+        want = O.trace(O.World(block), cam, 80, 60)
+        with core_for(block, mode) as g:
+            got = g.trace(cam, 80, 60)
+        assert_planes_equal(got, want, f"fill {fill}")
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_small_step_cap_is_honoured_exactly(mode):
+    block = np.zeros((256, 256, 256), np.uint8)
+    cam = scenes.cam16(scenes.pose_b())
+    want = O.trace(O.World(block, max_steps=37), cam, 64, 48)
+    assert (want["steps"] == 37).all() and (want["face"] == -2).all()
+    with core_for(block, mode, max_steps=37) as g:
+        got = g.trace(cam, 64, 48)
+    assert_planes_equal(got, want, "cap 37")
+
+
+def test_thousand_step_misses_are_teal():
+    n = 704
+    block = np.zeros((n, n, n), np.uint8)
+    block[:, 404, :] = 1  # a floor at world y = -300, so the world is not trivially empty
+    p = Player.at((16.5, 16.5, 16.5), -0.7853981, 0.6155)  # looks along (1,1,1): ~1048-step misses
+    cam = scenes.cam16(p)
+    want = O.trace(O.World(block), cam, 64, 48)
+    assert (want["steps"] >= 1000).any()
+    for mode in (TRACE_LITERAL, TRACE_SKIP):
+        with core_for(block, mode) as g:
+            got = g.trace(cam, 64, 48)
+        assert_planes_equal(got, want, "teal")
+
+
+def test_nonzero_distance_image_takes_the_literal_kernel():
+    rng = np.random.default_rng(11)
+    n = 64
+    block = ((rng.random((n, n, n)) < 0.01) * 3).astype(np.uint16)
+    dist = rng.integers(0, 4, (n, n, n)).astype(np.uint16)
+    cam = scenes.cam16(Player.at((10.2, 20.7, 5.5), 0.4, -0.3))
+    want = O.trace(O.World(block, dist), cam, 96, 64)
+    with GraphicsCore(grid_n=n) as g:  # AUTO
+        g.upload_world(block, dist)
+        got = g.trace(cam, 96, 64)
+        assert g.last_kernel_name() == "literal"
+        assert_planes_equal(got, want, "dist != 0")
+        # ≙ reset_distance_field: the image is cleared and the skip kernel becomes legal
+        g.reset_distance_field()
+        got = g.trace(cam, 96, 64)
+        assert g.last_kernel_name() == "skip"
+        assert_planes_equal(got, O.trace(O.World(block), cam, 96, 64), "after reset")
+    with GraphicsCore(grid_n=n, trace_mode=TRACE_SKIP) as g:
+        g.upload_world(block, dist)
+        with pytest.raises(VrtError) as e:
+            g.trace(cam, 96, 64)
+        assert e.value.code == -4
+
+
+def test_row_bands_and_strips_equal_the_full_frame(scene160):
+    cam = scenes.cam16(scenes.pose_b())
+    with core_for(scene160, TRACE_SKIP) as g:
+        full = g.trace(cam, 320, 240)
+        band = g.trace(cam, 320, 240, 100, 133)
+        for k in PLANES:
+            assert np.array_equal(full[k][100:133], band[k])
+        parts, sh = 3, 16
+        for part in range(parts):
+            got = g.trace_strips(cam, 320, 240, sh, part, parts, outputs=("bgra8", "steps"))
+            rows = np.concatenate([np.arange(s * sh, (s + 1) * sh) for s in range(part, 240 // sh, parts)])
+            assert np.array_equal(got["steps"], full["steps"][rows])
+            assert np.array_equal(got["bgra8"], full["bgra8"][rows])
+        zero = g.trace(cam, 320, 240, 7, 7)
+        assert zero["steps"].shape == (0, 320)
+
+
+def test_device_resident_outputs_match_host_outputs(scene160):
+    import torch
+    cam = scenes.cam16(scenes.pose_b())
+    w, h = 320, 240
+    with core_for(scene160, TRACE_SKIP) as g:
+        host = g.trace(cam, w, h)
+        dev = {"bgra8": torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda"),
+               "steps": torch.zeros((h, w), dtype=torch.int32, device="cuda"),
+               "voxel": torch.zeros((h, w, 3), dtype=torch.int32, device="cuda"),
+               "t": torch.zeros((h, w), dtype=torch.float32, device="cuda")}
+        torch.cuda.synchronize()
+        g.trace_device(cam, w, h, 0, h, {k: v.data_ptr() for k, v in dev.items()})
+        g.sync()
+        assert np.array_equal(dev["bgra8"].cpu().numpy(), host["bgra8"])
+        assert np.array_equal(dev["steps"].cpu().numpy().view(np.uint32), host["steps"])
+        assert np.array_equal(dev["voxel"].cpu().numpy(), host["voxel"])
+        assert np.array_equal(dev["t"].cpu().numpy().view(np.uint32), host["t"].view(np.uint32))
+        ms, launches = g.kernel_time()
+        assert launches == 2 and ms > 0
+
+
+def test_error_paths():
+    with GraphicsCore(grid_n=64) as g:
+        cam = scenes.cam16(scenes.pose_b())
+        with pytest.raises(VrtError) as e:
+            g.trace(cam, 64, 48)  # no world yet
+        assert e.value.code == -6
+        g.upload_world(np.zeros((64, 64, 64), np.uint16))
+        bad = cam.copy()
+        bad[12] = np.nan
+        with pytest.raises(VrtError):
+            g.trace(bad, 64, 48)
+        bad[12] = 3e7
+        with pytest.raises(VrtError):
+            g.trace(bad, 64, 48)
+        with pytest.raises(VrtError):
+            g.trace(cam, 64, 48, 10, 5)
+        with pytest.raises(VrtError):
+            g.trace(cam, 0, 48)

@@ -1,0 +1,59 @@
+"""GPU world producers against the CPU oracle: the terrain generator kernel
+(≙ upload_chunk_gpu, src/graphics/mod.rs:245-291 running terrain_gen.comp) must produce
+the same voxels bit for bit, so that hit-map parity never depends on who built the scene."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from raytracing_amd import GraphicsCore, TRACE_SKIP, VOXEL_PACKED_U8, VOXEL_REF_U16U16, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n,fmt,dtype", [(160, VOXEL_REF_U16U16, np.uint16), (256, VOXEL_PACKED_U8, np.uint8)])
+def test_generate_window_matches_oracle(n, fmt, dtype):
+    wmin = scenes.window_min(scenes.POSE_B_POSITION, n)
+    want = O.terrain_fill(n, wmin, dtype)
+    with GraphicsCore(grid_n=n, voxel_format=fmt) as g:
+        g.generate_window(wmin)
+        got = g.download_world()
+    assert got.dtype == want.dtype and np.array_equal(got, want)
+    assert 0.2 < want.astype(bool).mean() < 0.8
+
+
+def test_upload_chunks_around_player_builds_the_default_scene():
+    # GameState::new -> upload_chunks_around_player(None): 5^3 chunks around chunk (0,0,0)
+    # fill the whole 160^3 torus (src/game_logic/game_state.rs:50-83).
+    with GraphicsCore() as g:
+        assert g.grid_n == 160
+        count = g.upload_chunks_around_player((0.0, 0.0, 0.0), None)
+        assert count == 125
+        got = g.download_world()
+        want = O.terrain_fill(160, (-64, -64, -64), np.uint16)
+        assert np.array_equal(got, want)
+        # moving one chunk in +x regenerates only the newly exposed 25 chunks
+        count = g.upload_chunks_around_player((33.0, 0.0, 0.0), (0, 0, 0))
+        assert count == 25
+        got = g.download_world()
+        for cz in range(-2, 3):
+            for cy in range(-2, 3):
+                O.terrain_chunk(want, 3, cy, cz)
+        assert np.array_equal(got, want)
+        assert g.upload_chunks_around_player((40.0, 1.0, 2.0), (1, 0, 0)) == 0
+
+
+def test_generated_world_traces_like_uploaded_world():
+    p = scenes.pose_b()
+    wmin = scenes.window_min(p.get_position(), 160)
+    cam = scenes.cam16(p)
+    block = O.terrain_fill(160, wmin, np.uint16)
+    with GraphicsCore(trace_mode=TRACE_SKIP) as g:
+        g.generate_window(wmin)
+        g.reset_distance_field()
+        got = g.redraw(p.push_constants(), outputs=("bgra8", "voxel", "face", "steps", "t"))
+    full = O.trace(O.World(block), cam, 640, 480)
+    for k in got:
+        a, b = got[k], full[k]
+        if a.dtype == np.float32:
+            a, b = a.view(np.uint32), b.view(np.uint32)
+        assert np.array_equal(a, b), k

@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Headline benchmark: primary Mrays/s at 1920x1080 over a 1024^3 u8 voxel grid.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+One step = one full 1080p frame of primary rays (ray generation + traversal + shading +
+BGRA8 store) through libvrt.so.  The world (default procedural terrain over the 1024^3
+window around the camera) is generated on the GPU and indexed once, before timing, and
+stays resident in HBM.  With N > 1 every rank holds a replica of the world and traces a
+frame of its own camera pose (weak scaling); the BGRA8 framebuffers are gathered to rank
+0 over RCCL inside the timed region.
+
+Prints ONE JSON line on rank 0.  `roofline.achieved` = algorithmic bytes per launch /
+mean HIP-event duration of the trace kernel, where algorithmic bytes are what the
+reference's traversal reads and writes for the same frame: one voxel byte per loop
+iteration per ray (u8 layout, no distance image) + 4 bytes of BGRA8 per ray.
+`cpu_baseline` = the CPU oracle (a C restatement of the reference shader, not the
+reference itself) timed on a bounded sample of the same frame on this host's cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from raytracing_amd import GraphicsCore, Player, TRACE_AUTO, TRACE_LITERAL, TRACE_SKIP, VOXEL_PACKED_U8, scenes  # noqa: E402
+
+W, H, N_GRID = 1920, 1080, 1024
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+
+
+def rank_pose(rank, world):
+    """Rank r looks from the headline position with its yaw turned by 2*pi*r/world."""
+    base = scenes.pose_headline()
+    if world == 1:
+        return base
+    yaw = scenes.POSE_B_YAW + 2.0 * np.pi * rank / world
+    return Player.at(base.get_position(), yaw, scenes.POSE_B_PITCH)
+
+
+def cpu_baseline(core, cam, steps_plane):
+    """Oracle on every 4th 16-row strip of the frame (about a quarter of the rays)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    block = core.download_world()
+    world = O.World(block)
+    threads = O.host_threads()
+    strips = list(range(0, H // 16, 4))
+    rays = 0
+    t0 = time.perf_counter()
+    ok = True
+    for s in strips:
+        out = O.trace(world, cam, W, H, s * 16, min(H, s * 16 + 16), nthreads=threads, want=("bgra8", "steps"))
+        rays += out["steps"].size
+        ok = ok and np.array_equal(out["steps"], steps_plane[s * 16:s * 16 + 16])
+    dt = time.perf_counter() - t0
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"{len(strips)} of {H // 16} 16-row strips of the same 1080p frame ({rays} rays, {dt:.1f} s)",
+            "matches_gpu_steps": bool(ok)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--mode", choices=["auto", "skip", "literal"], default="auto")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    mode = {"auto": TRACE_AUTO, "skip": TRACE_SKIP, "literal": TRACE_LITERAL}[args.mode]
+    core = GraphicsCore(width=W, height=H, device=local_rank, grid_n=N_GRID, voxel_format=VOXEL_PACKED_U8,
+                        trace_mode=mode)
+    pose = rank_pose(rank, world)
+    cam = scenes.cam16(pose)
+    wmin = scenes.window_min(pose.get_position(), N_GRID)
+    t0 = time.perf_counter()
+    core.generate_window(wmin)          # world resident in HBM ...
+    core.reset_distance_field()         # ... and indexed, once, before timing
+    core.sync()
+    build_s = time.perf_counter() - t0
+
+    stream = torch.cuda.ExternalStream(core.stream(), device=torch.device("cuda", local_rank))
+    frame = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+    steps_t = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+    gathered = [torch.zeros_like(frame) for _ in range(world)] if (world > 1 and rank == 0) else None
+    torch.cuda.synchronize()
+
+    # untimed: step counts of this frame -> algorithmic bytes
+    core.trace_device(cam, W, H, 0, H, {"bgra8": frame.data_ptr(), "steps": steps_t.data_ptr()})
+    core.sync()
+    steps_np = steps_t.cpu().numpy().view(np.uint32)
+    sum_steps = int(steps_np.astype(np.int64).sum())
+    alg_bytes = sum_steps * 1 + W * H * 4
+
+    ptrs = {"bgra8": frame.data_ptr()}
+
+    def step():
+        core.trace_device(cam, W, H, 0, H, ptrs)
+        if world > 1:
+            with torch.cuda.stream(stream):
+                dist.gather(frame, gathered, dst=0)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        core.sync()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    core.kernel_time_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    kern_ms, launches = core.kernel_time()
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        rays = W * H * args.steps * world
+        kern_s = kern_ms / 1e3 / max(launches, 1)
+        achieved = alg_bytes / kern_s / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get(core.last_kernel_name())
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "primary Mrays/s at 1920x1080 on 1024^3 grid",
+            "value": rays / dt / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "1920x1080 primary rays over 1024^3 u8 procedural terrain (pose B at y=40.3), "
+                                   "world replicated per GPU, one pose per GPU, BGRA8 gather to rank 0",
+                       "kernel": core.last_kernel_name(), "grid_n": N_GRID, "width": W, "height": H,
+                       "world_build_s": round(build_s, 3)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_s * 1e3,
+                         "kernel_mrays_s": W * H / kern_s / 1e6, "mean_steps_per_ray": sum_steps / (W * H)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(core, cam, steps_np)
+        print(json.dumps(line), flush=True)
+
+    core.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -79,6 +79,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: build it with `make -C raytracing_amd/csrc` "
                               "(there is no CPU fallback for the trace path)")
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (same soname as
+        # the system one).  Loading torch first makes libvrt.so bind to that copy instead of
+        # bringing in a second runtime from /opt/rocm, which leaves torch unable to see the GPU.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)

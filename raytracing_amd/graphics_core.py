@@ -131,7 +131,7 @@ class GraphicsCore:
     def trace(self, cam, w, h, y0=0, y1=None, outputs=("bgra8", "voxel", "face", "steps", "t", "hit_point", "rgba")):
         """Trace rows [y0,y1) into fresh host arrays."""
         y1 = h if y1 is None else y1
-        rows = y1 - y0
+        rows = max(0, y1 - y0)  # an inverted band is rejected by the library, not here
         cam, camp = self._cam(cam)
         res = {}
         for k in outputs:

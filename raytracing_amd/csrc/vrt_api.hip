@@ -329,7 +329,6 @@ int vrt_trace_strips(vrt_ctx *c, const float cam[16], uint32_t w, uint32_t h, ui
                      uint32_t parts, const vrt_outputs *out)
 {
     if (strip_h == 0 || parts == 0 || part >= parts) return fail(VRT_E_INVALID_ARG, "bad strip partition");
-    if (h % strip_h != 0) return fail(VRT_E_INVALID_ARG, "frame height must be a multiple of strip_h");
     vrt::RowMap rows{0, vrt_strip_rows(h, strip_h, part, parts), strip_h, part, parts};
     return do_trace(c, cam, w, h, rows, out);
 }

@@ -1,0 +1,45 @@
+"""Multi-GPU sharding of one frame: interleaved row strips + framebuffer gather.
+
+Strip s covers image rows [s*strip_h, (s+1)*strip_h) and belongs to rank s % world, so sky
+and ground strips are dealt evenly (contiguous bands would give one rank all the long
+rays).  Each rank traces its strips packed in strip order (`vrt_trace_strips`); the only
+exchange is the gather of the packed buffers to one rank, followed by a row scatter.
+The reference has no counterpart (single device, src/graphics/mod.rs:325-342).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def strip_rows(h, strip_h, part, parts):
+    """Image rows traced by `part`, in packed order (matches vrt_trace_strips)."""
+    rows = [np.arange(s * strip_h, min(h, (s + 1) * strip_h)) for s in range(part, -(-h // strip_h), parts)]
+    return np.concatenate(rows) if rows else np.zeros(0, np.int64)
+
+
+def max_strip_rows(h, strip_h, parts):
+    return max(len(strip_rows(h, strip_h, p, parts)) for p in range(parts))
+
+
+def gather_frame(packed, h, strip_h, dst=0, group=None, out=None):
+    """Gather every rank's packed rows (tensor [rows_r, ...]) to `dst` and return the full
+    frame [h, ...] there (None elsewhere).  Ranks own different row counts when the strip
+    count is not a multiple of the world size, so buffers are padded to the largest."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    pad_rows = max_strip_rows(h, strip_h, world)
+    if packed.shape[0] != pad_rows:
+        buf = packed.new_zeros((pad_rows,) + tuple(packed.shape[1:]))
+        buf[:packed.shape[0]] = packed
+    else:
+        buf = packed
+    if rank == dst:
+        parts = [torch.empty_like(buf) for _ in range(world)]
+        dist.gather(buf, parts, dst=dst, group=group)
+        frame = out if out is not None else packed.new_empty((h,) + tuple(packed.shape[1:]))
+        for r in range(world):
+            rows = torch.as_tensor(strip_rows(h, strip_h, r, world), device=packed.device)
+            frame[rows] = parts[r][:len(rows)]
+        return frame
+    dist.gather(buf, None, dst=dst, group=group)
+    return None

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -135,6 +136,8 @@ int do_trace(vrt_ctx *c, const float *cam, uint32_t w, uint32_t h, const vrt::Ro
     p.n = (int)c->n;
     p.n_pow2_mask = (c->n & (c->n - 1)) == 0 ? (int)c->n - 1 : -1;
     p.max_steps = c->max_steps;
+    { const char *v = std::getenv("VRT_SKIP_VARIANT"); p.variant = v ? (uint32_t)std::atoi(v) : 0u; }  // A/B only
+    p.debug_iters = std::getenv("VRT_DEBUG_ITERS") ? 1u : 0u;  // diagnostic only
     p.block = c->d_block;
     p.dist = c->dist_nonzero ? c->d_dist : nullptr;
     p.cell_mask = c->d_mask; p.cell_df = c->d_df; p.nc = (int)c->n / 4;

@@ -24,6 +24,7 @@ struct RayHit {
     int      k;      // axis of the last step
     int      sk;     // s11 of that axis
     unsigned steps;
+    unsigned iters;  // iterations of the kernel's own loop (diagnostic)
     unsigned block_id;
     float    t, hx, hy, hz;
 };
@@ -104,7 +105,7 @@ VRT_DEV void traverse_literal(const TraceParams &P, float rox, float roy, float 
         cpy = wadd(wadd(ay, s01y), wmul(s11y, fd));
         cpz = wadd(wadd(az, s01z), wmul(s11z, fd));
     }
-    H.vx = ax; H.vy = ay; H.vz = az; H.steps = steps;
+    H.vx = ax; H.vy = ay; H.vz = az; H.steps = steps; H.iters = steps;
     if (!H.hit) { H.t = -1.0f; H.hx = H.hy = H.hz = 0.0f; }
 }
 
@@ -177,10 +178,12 @@ VRT_DEV void traverse_skip(const TraceParams &P, float rox, float roy, float roz
     int      cur_cell = -1, cur_d = 0;
     uint64_t cur_mask = 0;
     bool     have_mask = false;
+    unsigned iters = 0;
     for (;;) {
         const int cpx = ax + s01x, cpy = ay + s01y, cpz = az + s01z;
         if (!(lox < cpx && loy < cpy && loz < cpz && cpx < upx && cpy < upy && cpz < upz)) break;
         if (steps >= P.max_steps) { H.capped = 1; break; }
+        iters += (cur_d > 0 && cur_cell >= 0) ? 1u : 0x10001u;  // diagnostic: high half counts unit steps
         const int ux = ax - lox, uy = ay - loy, uz = az - loz;
         if (cur_cell < 0) {  // first iteration: the start voxel's cell
             int tx = ux + offx; tx -= tx >= n ? n : 0;
@@ -244,7 +247,150 @@ VRT_DEV void traverse_skip(const TraceParams &P, float rox, float roy, float roz
             }
         }
     }
-    H.vx = ax; H.vy = ay; H.vz = az; H.steps = steps;
+    H.vx = ax; H.vy = ay; H.vz = az; H.steps = steps; H.iters = iters;
+    if (!H.hit) { H.t = -1.0f; H.hx = H.hy = H.hz = 0.0f; }
+}
+
+// ---------------------------------------------------------------------------
+// exact empty-space skipping, second form: cheaper iterations
+// ---------------------------------------------------------------------------
+// Same visit order as traverse_skip.  Differences:
+//  * works in window-relative anchors u = a - lower, so the loop test is one unsigned
+//    range compare per axis;
+//  * a step inside a non-empty cell is a plain unit step that reuses the cell's mask
+//    from registers and only recomputes the cell when the step leaves it;
+//  * the per-axis event count of a box exit comes from floor(ro + rd*t_exit) whenever that
+//    point is provably on the right side of every plane: the sign of t_j(i) - t_exit
+//    equals the sign of (i - pos_j)/rd_j as soon as |pos_j - i| exceeds
+//    u*(3|i - ro_j| + |rd_j t| + |pos_j|) with u = 2^-24 (three roundings in t_j(i), two in
+//    pos_j); the kernel uses the wider margin 2^-20*(|rd_j t| + |pos_j| + 1).  Within the
+//    margin only the nearest plane is in doubt and it is settled by comparing t_j(i) with
+//    t_exit directly, with the reference's tie rule.
+
+// New window-relative anchor on a non-exit axis after leaving the box at (tk, k).
+VRT_DEV int axis_after_exit(float ro, float rd, float inv, int lo, int s01, int u, int bl, int bh, float tk,
+                            bool inclusive)
+{
+    const float rt  = rd * tk;
+    const float pos = ro + rt;
+    const float i0  = rintf(pos);
+    int a = f2i(floorf(pos));
+    const float eps = 0x1.0p-20f * ((fabsf(rt) + fabsf(pos)) + 1.0f);
+    if (fabsf(pos - i0) <= eps) {
+        const float tt      = (i0 - ro) * inv;  // t_j of the plane in doubt, as the reference computes it
+        const bool  crossed = inclusive ? tt <= tk : tt < tk;
+        a = f2i(i0) - ((crossed != (s01 != 0)) ? 1 : 0);
+    }
+    int un = a - lo;
+    un = min(max(un, bl), bh);
+    return s01 ? max(un, u) : min(un, u);
+}
+
+template <typename T>
+VRT_DEV void traverse_skip2(const TraceParams &P, float rox, float roy, float roz, float rdx, float rdy,
+                            float rdz, int lox, int loy, int loz, int upx, int upy, int upz, RayHit &H)
+{
+    const float invx = 1.0f / rdx, invy = 1.0f / rdy, invz = 1.0f / rdz;
+    const float big = 0x1.0p100f;
+    const bool regular = (rdx != 0.0f) && (rdy != 0.0f) && (rdz != 0.0f) && (fabsf(invx) < big) &&
+                         (fabsf(invy) < big) && (fabsf(invz) < big);
+    if (!regular) {
+        traverse_literal<T, false>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
+        return;
+    }
+    const int s01x = rdx > 0.0f ? 1 : 0, s01y = rdy > 0.0f ? 1 : 0, s01z = rdz > 0.0f ? 1 : 0;
+    const int s11x = 2 * s01x - 1, s11y = 2 * s01y - 1, s11z = 2 * s01z - 1;
+    const int n = P.n, nc = P.nc;
+    const int offx = rem_euclid(lox, n), offy = rem_euclid(loy, n), offz = rem_euclid(loz, n);
+    // loop test lower < a + s01 < upper  <=>  alo <= u <= ahi
+    const int alox = 1 - s01x, aloy = 1 - s01y, aloz = 1 - s01z;
+    const unsigned spanx = (unsigned)(n - 3), spany = spanx, spanz = spanx;  // ahi - alo
+    const int ahix = alox + (n - 3), ahiy = aloy + (n - 3), ahiz = aloz + (n - 3);
+    // world index of the next plane on each axis = u + pl
+    const int plx = lox + s01x, ply = loy + s01y, plz = loz + s01z;
+
+    int ux = f2i(floorf(rox)) - lox, uy = f2i(floorf(roy)) - loy, uz = f2i(floorf(roz)) - loz;
+    unsigned steps = 0, iters = 0;
+    H.hit = 0; H.capped = 0; H.block_id = 0; H.k = 0; H.sk = 0;
+    int      cur_cell = -1, d = 0;
+    uint64_t cur_mask = 0;
+    bool     have_mask = false;
+    for (;;) {
+        if ((unsigned)(ux - alox) > spanx || (unsigned)(uy - aloy) > spany || (unsigned)(uz - aloz) > spanz) break;
+        if (steps >= P.max_steps) { H.capped = 1; break; }
+        if (cur_cell < 0) {  // first iteration: the start voxel's cell (never tested for a hit)
+            int tx = ux + offx; tx -= tx >= n ? n : 0;
+            int ty = uy + offy; ty -= ty >= n ? n : 0;
+            int tz = uz + offz; tz -= tz >= n ? n : 0;
+            cur_cell = ((tz >> 2) * nc + (ty >> 2)) * nc + (tx >> 2);
+            d        = (int)P.cell_df[cur_cell];
+        }
+        int   k;
+        float tk;
+        bool  moved_cell;
+        if (d == 0 || steps + (unsigned)(24 * d) > P.max_steps) {
+            // unit step (raytrace.glsl:45-50 with a zero distance)
+            iters += 0x10001u;
+            const float tx = ((float)(ux + plx) - rox) * invx;
+            const float ty = ((float)(uy + ply) - roy) * invy;
+            const float tz = ((float)(uz + plz) - roz) * invz;
+            k  = argmin3(tx, ty, tz);
+            tk = k == 0 ? tx : (k == 1 ? ty : tz);
+            int oldu, newu;
+            if (k == 0) { oldu = ux; ux += s11x; newu = ux; }
+            else if (k == 1) { oldu = uy; uy += s11y; newu = uy; }
+            else { oldu = uz; uz += s11z; newu = uz; }
+            moved_cell = ((oldu ^ newu) & ~3) != 0;
+            steps += 1;
+        } else {
+            iters += 1u;
+            const int r = d - 1;
+            const int blx = max(((ux >> 2) - r) * 4, alox), bhx = min(((ux >> 2) + r) * 4 + 3, ahix);
+            const int bly = max(((uy >> 2) - r) * 4, aloy), bhy = min(((uy >> 2) + r) * 4 + 3, ahiy);
+            const int blz = max(((uz >> 2) - r) * 4, aloz), bhz = min(((uz >> 2) + r) * 4 + 3, ahiz);
+            // first anchor outside the box on each axis, and the plane crossed to get there
+            const int nux = s01x ? bhx + 1 : blx - 1, nuy = s01y ? bhy + 1 : bly - 1, nuz = s01z ? bhz + 1 : blz - 1;
+            const float tx = ((float)(nux + (lox + 1 - s01x)) - rox) * invx;
+            const float ty = ((float)(nuy + (loy + 1 - s01y)) - roy) * invy;
+            const float tz = ((float)(nuz + (loz + 1 - s01z)) - roz) * invz;
+            k  = argmin3(tx, ty, tz);
+            tk = k == 0 ? tx : (k == 1 ? ty : tz);
+            // axis j's events sort before the exit event of axis k on ties iff j < k
+            const int vx = k == 0 ? nux : axis_after_exit(rox, rdx, invx, lox, s01x, ux, blx, bhx, tk, true);
+            const int vy = k == 1 ? nuy : axis_after_exit(roy, rdy, invy, loy, s01y, uy, bly, bhy, tk, k == 2);
+            const int vz = k == 2 ? nuz : axis_after_exit(roz, rdz, invz, loz, s01z, uz, blz, bhz, tk, false);
+            steps += (unsigned)(abs(vx - ux) + abs(vy - uy) + abs(vz - uz));
+            ux = vx; uy = vy; uz = vz;
+            moved_cell = true;
+        }
+        // test the voxel just entered
+        if (moved_cell) {
+            int qx = ux + offx; qx -= qx >= n ? n : 0;
+            int qy = uy + offy; qy -= qy >= n ? n : 0;
+            int qz = uz + offz; qz -= qz >= n ? n : 0;
+            const int cell = ((qz >> 2) * nc + (qy >> 2)) * nc + (qx >> 2);
+            if (cell != cur_cell) {
+                cur_cell  = cell;
+                d         = (int)P.cell_df[cell];
+                have_mask = false;
+            }
+        }
+        if (d == 0) {
+            if (!have_mask) { cur_mask = P.cell_mask[cur_cell]; have_mask = true; }
+            const int bit = ((uz & 3) << 4) | ((uy & 3) << 2) | (ux & 3);  // off is a multiple of 4
+            if ((cur_mask >> bit) & 1ull) {
+                H.hit = 1; H.k = k; H.sk = k == 0 ? s11x : (k == 1 ? s11y : s11z);
+                H.t = tk;
+                H.hx = rox + rdx * tk; H.hy = roy + rdy * tk; H.hz = roz + rdz * tk;
+                int qx = ux + offx; qx -= qx >= n ? n : 0;
+                int qy = uy + offy; qy -= qy >= n ? n : 0;
+                int qz = uz + offz; qz -= qz >= n ? n : 0;
+                H.block_id = (unsigned)((const T *)P.block)[((size_t)qz * (size_t)n + (size_t)qy) * (size_t)n + (size_t)qx];
+                break;
+            }
+        }
+    }
+    H.vx = ux + lox; H.vy = uy + loy; H.vz = uz + loz; H.steps = steps; H.iters = iters;
     if (!H.hit) { H.t = -1.0f; H.hx = H.hy = H.hz = 0.0f; }
 }
 
@@ -303,7 +449,7 @@ VRT_DEV void finish_pixel(const TraceParams &P, unsigned gx, unsigned gy, size_t
     }
     if (P.voxel) { P.voxel[3 * i] = H.vx; P.voxel[3 * i + 1] = H.vy; P.voxel[3 * i + 2] = H.vz; }
     if (P.face) P.face[i] = H.hit ? 2 * H.k + (H.sk < 0 ? 1 : 0) : (H.capped ? -2 : -1);
-    if (P.steps) P.steps[i] = H.steps;
+    if (P.steps) P.steps[i] = P.debug_iters ? H.iters : H.steps;
     if (P.t) P.t[i] = H.t;
     if (P.hit_point) { P.hit_point[3 * i] = H.hx; P.hit_point[3 * i + 1] = H.hy; P.hit_point[3 * i + 2] = H.hz; }
     if (P.rgba) { P.rgba[4 * i] = r; P.rgba[4 * i + 1] = g; P.rgba[4 * i + 2] = b; P.rgba[4 * i + 3] = a; }
@@ -325,7 +471,7 @@ __global__ __launch_bounds__(256) void k_trace_literal(const TraceParams P)
     finish_pixel(P, gx, gy, (size_t)q * P.w + col, H);
 }
 
-template <typename T>
+template <typename T, int VARIANT>
 __global__ __launch_bounds__(256) void k_trace_skip(const TraceParams P)
 {
     unsigned col, q, row;
@@ -337,7 +483,8 @@ __global__ __launch_bounds__(256) void k_trace_skip(const TraceParams P)
     int lox, loy, loz, upx, upy, upz;
     loaded_area(P, rox, lox, upx); loaded_area(P, roy, loy, upy); loaded_area(P, roz, loz, upz);
     RayHit H;
-    traverse_skip<T>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
+    if (VARIANT == 1) traverse_skip<T>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
+    else traverse_skip2<T>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
     finish_pixel(P, gx, gy, (size_t)q * P.w + col, H);
 }
 
@@ -361,8 +508,13 @@ hipError_t launch_trace_skip(const TraceParams &p, int voxel_bytes, hipStream_t 
 {
     if (p.rows.rows == 0 || p.w == 0) return hipSuccess;
     const dim3 grid = trace_grid(p), block(256);
-    if (voxel_bytes == 1) k_trace_skip<uint8_t><<<grid, block, 0, s>>>(p);
-    else k_trace_skip<uint16_t><<<grid, block, 0, s>>>(p);
+    if (p.variant == 1) {  // first form of the skip traversal, kept for A/B measurements
+        if (voxel_bytes == 1) k_trace_skip<uint8_t, 1><<<grid, block, 0, s>>>(p);
+        else k_trace_skip<uint16_t, 1><<<grid, block, 0, s>>>(p);
+    } else {
+        if (voxel_bytes == 1) k_trace_skip<uint8_t, 2><<<grid, block, 0, s>>>(p);
+        else k_trace_skip<uint16_t, 2><<<grid, block, 0, s>>>(p);
+    }
     return hipGetLastError();
 }
 

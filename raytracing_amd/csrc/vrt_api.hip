@@ -55,6 +55,8 @@ struct vrt_ctx {
     uint64_t   *d_mask       = nullptr;  // (n/4)^3
     uint8_t    *d_df         = nullptr;  // (n/4)^3
     uint8_t    *d_df_tmp     = nullptr;
+    uint8_t    *d_odf        = nullptr;  // 8 x (n/4)^3 octant distance fields
+    uint8_t    *d_odf_tmp    = nullptr;  // 3 x (n/4)^3
     bool        skip_valid   = false;
     uint32_t   *d_flag       = nullptr;
     // staging for host-resident outputs
@@ -93,9 +95,12 @@ int ensure_skip_structure(vrt_ctx *c)
         HIP_TRY(hipMalloc(&c->d_mask, cells(c) * sizeof(uint64_t)));
         HIP_TRY(hipMalloc(&c->d_df, cells(c)));
         HIP_TRY(hipMalloc(&c->d_df_tmp, cells(c)));
+        HIP_TRY(hipMalloc(&c->d_odf, 8 * cells(c)));
+        HIP_TRY(hipMalloc(&c->d_odf_tmp, 3 * cells(c)));
     }
     HIP_TRY(vrt::launch_build_masks(c->d_block, c->voxel_bytes, (int)c->n, c->d_mask, c->stream));
     HIP_TRY(vrt::launch_build_df(c->d_mask, (int)c->n / 4, c->d_df, c->d_df_tmp, c->stream));
+    HIP_TRY(vrt::launch_build_octant_df(c->d_mask, (int)c->n / 4, c->d_odf, c->d_odf_tmp, c->stream));
     c->skip_valid = true;
     return VRT_OK;
 }
@@ -137,10 +142,10 @@ int do_trace(vrt_ctx *c, const float *cam, uint32_t w, uint32_t h, const vrt::Ro
     p.n_pow2_mask = (c->n & (c->n - 1)) == 0 ? (int)c->n - 1 : -1;
     p.max_steps = c->max_steps;
     { const char *v = std::getenv("VRT_SKIP_VARIANT"); p.variant = v ? (uint32_t)std::atoi(v) : 0u; }  // A/B only
-    p.debug_iters = std::getenv("VRT_DEBUG_ITERS") ? 1u : 0u;  // diagnostic only
+    { const char *v = std::getenv("VRT_DEBUG_ITERS"); p.debug_iters = v ? (uint32_t)std::atoi(v) : 0u; }  // diagnostic only
     p.block = c->d_block;
     p.dist = c->dist_nonzero ? c->d_dist : nullptr;
-    p.cell_mask = c->d_mask; p.cell_df = c->d_df; p.nc = (int)c->n / 4;
+    p.cell_mask = c->d_mask; p.cell_df = c->d_df; p.cell_odf = c->d_odf; p.nc = (int)c->n / 4;
 
     const size_t px = (size_t)rows.rows * w;
     Plane planes[7] = {{0, out->bgra8 ? px * 4 : 0, out->bgra8},       {0, out->voxel ? px * 12 : 0, out->voxel},
@@ -236,7 +241,7 @@ int vrt_destroy(vrt_ctx *c)
         if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]);
         if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]);
     }
-    void *bufs[] = {c->d_block, c->d_dist, c->d_mask, c->d_df, c->d_df_tmp, c->d_flag, c->d_stage};
+    void *bufs[] = {c->d_block, c->d_dist, c->d_mask, c->d_df, c->d_df_tmp, c->d_odf, c->d_odf_tmp, c->d_flag, c->d_stage};
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

@@ -16,15 +16,19 @@ namespace vrt {
 
 constexpr int kChunk = 32;  // raytrace.glsl:10, terrain_gen.comp:12
 
-// float -> int: saturating, NaN -> 0 (what v_cvt_i32_f32 does; spelled out so that the
-// optimiser never sees an out-of-range fptosi).
+// float -> int: saturating, NaN -> 0.  This is exactly what the hardware conversion
+// v_cvt_i32_f32 does (round toward zero, out-of-range values saturate, NaN gives 0); the
+// instruction is issued directly so that the optimiser never sees an out-of-range fptosi
+// (undefined in C++) and no compare/branch cascade is needed.
 VRT_DEV int f2i(float x)
 {
-    if (x != x) return 0;
-    if (x >= 2147483648.0f) return 2147483647;
-    if (x <= -2147483648.0f) return -2147483647 - 1;
-    return (int)x;
+    int r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
 }
+
+// float -> int for values known to be finite and far inside the int range.
+VRT_DEV int f2i_small(float x) { return (int)x; }
 
 // wrapping integer arithmetic
 VRT_DEV int wadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }

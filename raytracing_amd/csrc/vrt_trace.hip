@@ -268,25 +268,25 @@ VRT_DEV void traverse_skip(const TraceParams &P, float rox, float roy, float roz
 //    t_exit directly, with the reference's tie rule.
 
 // New window-relative anchor on a non-exit axis after leaving the box at (tk, k).
+// Branch free: every lane evaluates the plane in doubt and selects.
 VRT_DEV int axis_after_exit(float ro, float rd, float inv, int lo, int s01, int u, int bl, int bh, float tk,
                             bool inclusive)
 {
-    const float rt  = rd * tk;
-    const float pos = ro + rt;
-    const float i0  = rintf(pos);
-    int a = f2i(floorf(pos));
-    const float eps = 0x1.0p-20f * ((fabsf(rt) + fabsf(pos)) + 1.0f);
-    if (fabsf(pos - i0) <= eps) {
-        const float tt      = (i0 - ro) * inv;  // t_j of the plane in doubt, as the reference computes it
-        const bool  crossed = inclusive ? tt <= tk : tt < tk;
-        a = f2i(i0) - ((crossed != (s01 != 0)) ? 1 : 0);
-    }
+    const float rt   = rd * tk;
+    const float pos  = ro + rt;
+    const float i0   = rintf(pos);
+    const float eps  = 0x1.0p-20f * ((fabsf(rt) + fabsf(pos)) + 1.0f);
+    const float tt   = (i0 - ro) * inv;  // t_j of the nearest plane, as the reference computes it
+    const bool  crossed = inclusive ? tt <= tk : tt < tk;
+    const int   a_near  = f2i_small(i0) - ((crossed != (s01 != 0)) ? 1 : 0);
+    const int   a_far   = f2i_small(floorf(pos));
+    const int   a       = fabsf(pos - i0) <= eps ? a_near : a_far;
     int un = a - lo;
     un = min(max(un, bl), bh);
     return s01 ? max(un, u) : min(un, u);
 }
 
-template <typename T>
+template <typename T, bool OCT>
 VRT_DEV void traverse_skip2(const TraceParams &P, float rox, float roy, float roz, float rdx, float rdy,
                             float rdz, int lox, int loy, int loz, int upx, int upy, int upz, RayHit &H)
 {
@@ -309,7 +309,15 @@ VRT_DEV void traverse_skip2(const TraceParams &P, float rox, float roy, float ro
     // world index of the next plane on each axis = u + pl
     const int plx = lox + s01x, ply = loy + s01y, plz = loz + s01z;
 
-    int ux = f2i(floorf(rox)) - lox, uy = f2i(floorf(roy)) - loy, uz = f2i(floorf(roz)) - loz;
+    // OCT: the distance field of the ray's own octant -- distance d means the d^3 cells that
+    // start at the current cell and extend in the ray's direction are empty; otherwise the
+    // isotropic field -- the (2d-1)^3 cells centred on the current cell are empty.
+    const uint8_t *df = OCT ? P.cell_odf + (size_t)(s01x | (s01y << 1) | (s01z << 2)) * ((size_t)nc * nc * nc) : P.cell_df;
+    const int mlx = OCT ? 1 - s01x : 1, mhx = OCT ? s01x : 1;
+    const int mly = OCT ? 1 - s01y : 1, mhy = OCT ? s01y : 1;
+    const int mlz = OCT ? 1 - s01z : 1, mhz = OCT ? s01z : 1;
+
+    int ux = f2i_small(floorf(rox)) - lox, uy = f2i_small(floorf(roy)) - loy, uz = f2i_small(floorf(roz)) - loz;
     unsigned steps = 0, iters = 0;
     H.hit = 0; H.capped = 0; H.block_id = 0; H.k = 0; H.sk = 0;
     int      cur_cell = -1, d = 0;
@@ -323,31 +331,30 @@ VRT_DEV void traverse_skip2(const TraceParams &P, float rox, float roy, float ro
             int ty = uy + offy; ty -= ty >= n ? n : 0;
             int tz = uz + offz; tz -= tz >= n ? n : 0;
             cur_cell = ((tz >> 2) * nc + (ty >> 2)) * nc + (tx >> 2);
-            d        = (int)P.cell_df[cur_cell];
+            d        = (int)df[cur_cell];
         }
         int   k;
         float tk;
         bool  moved_cell;
         if (d == 0 || steps + (unsigned)(24 * d) > P.max_steps) {
             // unit step (raytrace.glsl:45-50 with a zero distance)
-            iters += 0x10001u;
+            iters += P.debug_iters == 2 ? 0u : 0x10001u;
             const float tx = ((float)(ux + plx) - rox) * invx;
             const float ty = ((float)(uy + ply) - roy) * invy;
             const float tz = ((float)(uz + plz) - roz) * invz;
             k  = argmin3(tx, ty, tz);
             tk = k == 0 ? tx : (k == 1 ? ty : tz);
-            int oldu, newu;
-            if (k == 0) { oldu = ux; ux += s11x; newu = ux; }
-            else if (k == 1) { oldu = uy; uy += s11y; newu = uy; }
-            else { oldu = uz; uz += s11z; newu = uz; }
+            const int oldu = k == 0 ? ux : (k == 1 ? uy : uz);
+            const int newu = oldu + (k == 0 ? s11x : (k == 1 ? s11y : s11z));
+            ux = k == 0 ? newu : ux; uy = k == 1 ? newu : uy; uz = k == 2 ? newu : uz;
             moved_cell = ((oldu ^ newu) & ~3) != 0;
             steps += 1;
         } else {
-            iters += 1u;
+            iters += P.debug_iters == 2 ? (d == 1 ? 1u : (d == 2 ? 0x100u : (d <= 4 ? 0x10000u : 0x1000000u))) : 1u;
             const int r = d - 1;
-            const int blx = max(((ux >> 2) - r) * 4, alox), bhx = min(((ux >> 2) + r) * 4 + 3, ahix);
-            const int bly = max(((uy >> 2) - r) * 4, aloy), bhy = min(((uy >> 2) + r) * 4 + 3, ahiy);
-            const int blz = max(((uz >> 2) - r) * 4, aloz), bhz = min(((uz >> 2) + r) * 4 + 3, ahiz);
+            const int blx = max(((ux >> 2) - r * mlx) * 4, alox), bhx = min(((ux >> 2) + r * mhx) * 4 + 3, ahix);
+            const int bly = max(((uy >> 2) - r * mly) * 4, aloy), bhy = min(((uy >> 2) + r * mhy) * 4 + 3, ahiy);
+            const int blz = max(((uz >> 2) - r * mlz) * 4, aloz), bhz = min(((uz >> 2) + r * mhz) * 4 + 3, ahiz);
             // first anchor outside the box on each axis, and the plane crossed to get there
             const int nux = s01x ? bhx + 1 : blx - 1, nuy = s01y ? bhy + 1 : bly - 1, nuz = s01z ? bhz + 1 : blz - 1;
             const float tx = ((float)(nux + (lox + 1 - s01x)) - rox) * invx;
@@ -356,9 +363,10 @@ VRT_DEV void traverse_skip2(const TraceParams &P, float rox, float roy, float ro
             k  = argmin3(tx, ty, tz);
             tk = k == 0 ? tx : (k == 1 ? ty : tz);
             // axis j's events sort before the exit event of axis k on ties iff j < k
-            const int vx = k == 0 ? nux : axis_after_exit(rox, rdx, invx, lox, s01x, ux, blx, bhx, tk, true);
-            const int vy = k == 1 ? nuy : axis_after_exit(roy, rdy, invy, loy, s01y, uy, bly, bhy, tk, k == 2);
-            const int vz = k == 2 ? nuz : axis_after_exit(roz, rdz, invz, loz, s01z, uz, blz, bhz, tk, false);
+            const int wx = axis_after_exit(rox, rdx, invx, lox, s01x, ux, blx, bhx, tk, true);
+            const int wy = axis_after_exit(roy, rdy, invy, loy, s01y, uy, bly, bhy, tk, k == 2);
+            const int wz = axis_after_exit(roz, rdz, invz, loz, s01z, uz, blz, bhz, tk, false);
+            const int vx = k == 0 ? nux : wx, vy = k == 1 ? nuy : wy, vz = k == 2 ? nuz : wz;
             steps += (unsigned)(abs(vx - ux) + abs(vy - uy) + abs(vz - uz));
             ux = vx; uy = vy; uz = vz;
             moved_cell = true;
@@ -371,7 +379,7 @@ VRT_DEV void traverse_skip2(const TraceParams &P, float rox, float roy, float ro
             const int cell = ((qz >> 2) * nc + (qy >> 2)) * nc + (qx >> 2);
             if (cell != cur_cell) {
                 cur_cell  = cell;
-                d         = (int)P.cell_df[cell];
+                d         = (int)df[cell];
                 have_mask = false;
             }
         }
@@ -484,7 +492,8 @@ __global__ __launch_bounds__(256) void k_trace_skip(const TraceParams P)
     loaded_area(P, rox, lox, upx); loaded_area(P, roy, loy, upy); loaded_area(P, roz, loz, upz);
     RayHit H;
     if (VARIANT == 1) traverse_skip<T>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
-    else traverse_skip2<T>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
+    else if (VARIANT == 2) traverse_skip2<T, false>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
+    else traverse_skip2<T, true>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
     finish_pixel(P, gx, gy, (size_t)q * P.w + col, H);
 }
 
@@ -511,9 +520,12 @@ hipError_t launch_trace_skip(const TraceParams &p, int voxel_bytes, hipStream_t 
     if (p.variant == 1) {  // first form of the skip traversal, kept for A/B measurements
         if (voxel_bytes == 1) k_trace_skip<uint8_t, 1><<<grid, block, 0, s>>>(p);
         else k_trace_skip<uint16_t, 1><<<grid, block, 0, s>>>(p);
-    } else {
+    } else if (p.variant == 2) {  // isotropic distance field
         if (voxel_bytes == 1) k_trace_skip<uint8_t, 2><<<grid, block, 0, s>>>(p);
         else k_trace_skip<uint16_t, 2><<<grid, block, 0, s>>>(p);
+    } else {
+        if (voxel_bytes == 1) k_trace_skip<uint8_t, 3><<<grid, block, 0, s>>>(p);
+        else k_trace_skip<uint16_t, 3><<<grid, block, 0, s>>>(p);
     }
     return hipGetLastError();
 }

@@ -208,6 +208,55 @@ hipError_t launch_build_df(const uint64_t *cell_mask, int nc, uint8_t *df_a, uin
     return hipGetLastError();
 }
 
+// One axis of the octant transform: out(p) = min over r >= 0 of max(r, in(p + dir*r)) along
+// `axis` (torus).  Applied along x, y, z with directions (sx, sy, sz) to in = {0 non-empty,
+// 255 empty} it yields the Chebyshev distance to the nearest non-empty cell q with
+// s_k*(q_k - c_k) >= 0 on every axis, i.e. the side of the largest empty cube of cells that
+// has the cell at its corner and extends into that octant.
+template <bool FROM_MASK>
+__global__ __launch_bounds__(256) void k_df_dir_pass(const uint64_t *cell_mask, const uint8_t *in, uint8_t *out, int nc,
+                                                     int axis, int dir)
+{
+    const int cx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int cy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int cz = blockIdx.z;
+    if (cx >= nc || cy >= nc) return;
+    const size_t self = ((size_t)cz * nc + cy) * nc + cx;
+    auto value = [&](size_t i) -> int {
+        if (FROM_MASK) return cell_mask[i] != 0 ? 0 : 255;
+        return (int)in[i];
+    };
+    const int    pos    = axis == 0 ? cx : (axis == 1 ? cy : cz);
+    const size_t stride = axis == 0 ? 1 : (axis == 1 ? (size_t)nc : (size_t)nc * nc);
+    const size_t line   = self - (size_t)pos * stride;
+    int best = value(self);
+    for (int r = 1; r < best && r < nc; ++r) {
+        int q = pos + dir * r;
+        q += q < 0 ? nc : 0;
+        q -= q >= nc ? nc : 0;
+        best = min(best, max(r, value(line + (size_t)q * stride)));
+    }
+    out[self] = (uint8_t)best;
+}
+
+hipError_t launch_build_octant_df(const uint64_t *cell_mask, int nc, uint8_t *odf, uint8_t *tmp, hipStream_t s)
+{
+    const dim3   grid((nc + 63) / 64, (nc + 3) / 4, nc), blockdim(256);
+    const size_t cells = (size_t)nc * nc * nc;
+    uint8_t *tx = tmp, *ty0 = tmp + cells, *ty1 = tmp + 2 * cells;
+    for (int sx = 0; sx < 2; ++sx) {
+        k_df_dir_pass<true><<<grid, blockdim, 0, s>>>(cell_mask, nullptr, tx, nc, 0, sx ? 1 : -1);
+        k_df_dir_pass<false><<<grid, blockdim, 0, s>>>(nullptr, tx, ty0, nc, 1, -1);
+        k_df_dir_pass<false><<<grid, blockdim, 0, s>>>(nullptr, tx, ty1, nc, 1, 1);
+        for (int sy = 0; sy < 2; ++sy)
+            for (int sz = 0; sz < 2; ++sz)
+                k_df_dir_pass<false><<<grid, blockdim, 0, s>>>(nullptr, sy ? ty1 : ty0,
+                                                               odf + (size_t)(sx | (sy << 1) | (sz << 2)) * cells, nc, 2,
+                                                               sz ? 1 : -1);
+    }
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_any_nonzero(const uint16_t *p, size_t count, uint32_t *flag)
 {

@@ -52,11 +52,7 @@ struct vrt_ctx {
     bool        dist_nonzero = false;
     bool        have_world   = false;
     // skip structure
-    uint64_t   *d_mask       = nullptr;  // (n/4)^3
-    uint8_t    *d_df         = nullptr;  // (n/4)^3
-    uint8_t    *d_df_tmp     = nullptr;
-    uint8_t    *d_odf        = nullptr;  // 8 x (n/4)^3 octant distance fields
-    uint8_t    *d_odf_tmp    = nullptr;  // 3 x (n/4)^3
+    uint4      *d_cells      = nullptr;  // (n/4)^3 records: occupancy mask + octant distances
     bool        skip_valid   = false;
     uint32_t   *d_flag       = nullptr;
     // staging for host-resident outputs
@@ -91,16 +87,15 @@ int drain_events(vrt_ctx *c)
 int ensure_skip_structure(vrt_ctx *c)
 {
     if (c->skip_valid) return VRT_OK;
-    if (!c->d_mask) {
-        HIP_TRY(hipMalloc(&c->d_mask, cells(c) * sizeof(uint64_t)));
-        HIP_TRY(hipMalloc(&c->d_df, cells(c)));
-        HIP_TRY(hipMalloc(&c->d_df_tmp, cells(c)));
-        HIP_TRY(hipMalloc(&c->d_odf, 8 * cells(c)));
-        HIP_TRY(hipMalloc(&c->d_odf_tmp, 3 * cells(c)));
-    }
-    HIP_TRY(vrt::launch_build_masks(c->d_block, c->voxel_bytes, (int)c->n, c->d_mask, c->stream));
-    HIP_TRY(vrt::launch_build_df(c->d_mask, (int)c->n / 4, c->d_df, c->d_df_tmp, c->stream));
-    HIP_TRY(vrt::launch_build_octant_df(c->d_mask, (int)c->n / 4, c->d_odf, c->d_odf_tmp, c->stream));
+    if (!c->d_cells) HIP_TRY(hipMalloc(&c->d_cells, cells(c) * sizeof(uint4)));
+    // scratch for the separable distance passes: released again, the build is not a hot path
+    uint8_t *tmp = nullptr;
+    HIP_TRY(hipMalloc(&tmp, 11 * cells(c)));
+    hipError_t e = vrt::launch_build_cells(c->d_block, c->voxel_bytes, (int)c->n, c->d_cells, tmp, c->stream);
+    hipError_t e2 = hipStreamSynchronize(c->stream);
+    (void)hipFree(tmp);
+    HIP_TRY(e);
+    HIP_TRY(e2);
     c->skip_valid = true;
     return VRT_OK;
 }
@@ -145,7 +140,7 @@ int do_trace(vrt_ctx *c, const float *cam, uint32_t w, uint32_t h, const vrt::Ro
     { const char *v = std::getenv("VRT_DEBUG_ITERS"); p.debug_iters = v ? (uint32_t)std::atoi(v) : 0u; }  // diagnostic only
     p.block = c->d_block;
     p.dist = c->dist_nonzero ? c->d_dist : nullptr;
-    p.cell_mask = c->d_mask; p.cell_df = c->d_df; p.cell_odf = c->d_odf; p.nc = (int)c->n / 4;
+    p.cells = c->d_cells; p.nc = (int)c->n / 4;
 
     const size_t px = (size_t)rows.rows * w;
     Plane planes[7] = {{0, out->bgra8 ? px * 4 : 0, out->bgra8},       {0, out->voxel ? px * 12 : 0, out->voxel},
@@ -241,7 +236,7 @@ int vrt_destroy(vrt_ctx *c)
         if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]);
         if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]);
     }
-    void *bufs[] = {c->d_block, c->d_dist, c->d_mask, c->d_df, c->d_df_tmp, c->d_odf, c->d_odf_tmp, c->d_flag, c->d_stage};
+    void *bufs[] = {c->d_block, c->d_dist, c->d_cells, c->d_flag, c->d_stage};
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

@@ -29,12 +29,12 @@ struct TraceParams {
     // world
     const void     *block;  // n^3 texels (u8 or u16), linear x fastest
     const uint16_t *dist;   // n^3 texels or nullptr (all zero)
-    // skip structure (cells of 4^3 voxels, torus space)
-    const uint64_t *cell_mask;  // (n/4)^3 occupancy masks, bit = (z&3)*16 + (y&3)*4 + (x&3)
-    const uint8_t  *cell_df;    // (n/4)^3 Chebyshev distance (in cells) to the nearest non-empty cell, 0 = non-empty
-    const uint8_t  *cell_odf;   // 8 x (n/4)^3: per direction octant o = sx | sy<<1 | sz<<2 (bit set = positive
-                                // direction), side of the largest empty cube of cells that starts at the cell
-                                // and extends into that octant; 0 = the cell is non-empty, cap 255
+    // skip structure: one 16-byte record per cell of 4^3 voxels (torus space, linear order)
+    //   .x,.y  64-bit occupancy mask, bit = (z&3)*16 + (y&3)*4 + (x&3)
+    //   .z,.w  eight octant distances, byte o = sx | sy<<1 | sz<<2 (bit set = positive direction):
+    //          side of the largest empty cube of cells that starts at the cell and extends into
+    //          that octant; 0 = the cell is non-empty, cap 255
+    const uint4 *cells;
     int32_t  nc;                // n / 4
     // outputs (device pointers, any may be null)
     uint8_t  *bgra8;
@@ -53,10 +53,8 @@ hipError_t launch_trace_skip(const TraceParams &p, int voxel_bytes, hipStream_t 
 // world kernels
 hipError_t launch_terrain(void *block, int voxel_bytes, int n, int x0, int y0, int z0,
                           int ex, int ey, int ez, hipStream_t s);
-hipError_t launch_build_masks(const void *block, int voxel_bytes, int n, uint64_t *cell_mask, hipStream_t s);
-hipError_t launch_build_df(const uint64_t *cell_mask, int nc, uint8_t *df_a, uint8_t *df_b, hipStream_t s);
-// octant fields: odf = 8 x nc^3 bytes, tmp = 3 x nc^3 bytes
-hipError_t launch_build_octant_df(const uint64_t *cell_mask, int nc, uint8_t *odf, uint8_t *tmp, hipStream_t s);
+// cells = nc^3 records; tmp = 11 * nc^3 bytes of scratch
+hipError_t launch_build_cells(const void *block, int voxel_bytes, int n, uint4 *cells, uint8_t *tmp, hipStream_t s);
 hipError_t launch_any_nonzero_u16(const uint16_t *p, size_t count, uint32_t *flag, hipStream_t s);
 
 }  // namespace vrt

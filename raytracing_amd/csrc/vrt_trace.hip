@@ -6,9 +6,9 @@
 //   k_trace_literal : one voxel per iteration, straight restatement of
 //                     raytrace.glsl:26-77 (reads the linear block / distance images).
 //   k_trace_skip    : the same visit order reproduced exactly, but empty space is
-//                     crossed in one iteration per empty box.  Reads a 1-byte cell
-//                     distance field and 64-bit 4^3 occupancy masks instead of one
-//                     voxel per step; the voxel image is read once, at the hit.
+//                     crossed in one iteration per empty box.  Reads one 16-byte record
+//                     per 4^3 cell visited (occupancy mask + octant distances) instead
+//                     of one voxel per step; the voxel image is read once, at the hit.
 //
 // Reference lines followed: render.comp:6-14 (entry, crosshair, flipped store),
 // raytrace.glsl:19-24 (loaded area), :26-77 (traversal), :117-134 (ray generation,
@@ -119,153 +119,20 @@ VRT_DEV void traverse_literal(const TraceParams &P, float rox, float roy, float 
 // merge of three sorted event lists under the key (t, axis).  Crossing an empty
 // axis-aligned box can therefore be done in one go: the exit event is the smallest
 // (t, axis) among the three exit planes, and every other axis advances by the number of
-// its events that sort before the exit event -- found by an estimate from the exit
-// point and corrected against t_j(i) itself, which makes the count exact.
-
-// Number of events m = 0,1,.. on one axis (plane cp + s11*m) that sort before (tstar, kstar):
-// t < tstar, or t <= tstar when this axis has the lower index.  `maxm` = events strictly
-// inside the box (the exit plane itself never sorts before the exit event).
-VRT_DEV int events_before(float ro, float rd, float inv, int cp, int s11, int a, int lo, int hi,
-                          float tstar, bool inclusive, int maxm)
-{
-    int ae = f2i(floorf(ro + rd * tstar));
-    ae     = min(max(ae, lo), hi);
-    int m  = s11 > 0 ? ae - a : a - ae;
-    m      = min(max(m, 0), maxm);
-    for (;;) {  // grow while event m still sorts before the exit event
-        if (m >= maxm) break;
-        const float tt = ((float)(cp + s11 * m) - ro) * inv;
-        if (!(inclusive ? tt <= tstar : tt < tstar)) break;
-        ++m;
-    }
-    for (;;) {  // shrink while event m-1 does not
-        if (m <= 0) break;
-        const float tt = ((float)(cp + s11 * (m - 1)) - ro) * inv;
-        if (inclusive ? tt <= tstar : tt < tstar) break;
-        --m;
-    }
-    return m;
-}
-
-template <typename T>
-VRT_DEV void traverse_skip(const TraceParams &P, float rox, float roy, float roz, float rdx, float rdy,
-                           float rdz, int lox, int loy, int loz, int upx, int upy, int upz, RayHit &H)
-{
-    const float invx = 1.0f / rdx, invy = 1.0f / rdy, invz = 1.0f / rdz;
-    // The box algebra needs finite, non-zero directions and finite plane parameters.
-    // Anything else takes the literal loop (NaN / inf semantics of the reference).
-    const float big = 0x1.0p100f;
-    const bool regular = (rdx != 0.0f) && (rdy != 0.0f) && (rdz != 0.0f) && (fabsf(invx) < big) &&
-                         (fabsf(invy) < big) && (fabsf(invz) < big);
-    if (!regular) {
-        traverse_literal<T, false>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
-        return;
-    }
-    const int s01x = rdx > 0.0f ? 1 : 0, s01y = rdy > 0.0f ? 1 : 0, s01z = rdz > 0.0f ? 1 : 0;
-    const int s11x = 2 * s01x - 1, s11y = 2 * s01y - 1, s11z = 2 * s01z - 1;
-    const int n = P.n, nc = P.nc;
-    // window-relative coordinate u = a - lower lies in [0, n-2] whenever the loop test holds;
-    // its texel is u + off (mod n) with off = rem_euclid(lower, n), a multiple of 4.
-    const int offx = rem_euclid(lox, n), offy = rem_euclid(loy, n), offz = rem_euclid(loz, n);
-    // anchors a for which the loop test (lower < a + s01 < upper) holds, window relative
-    const int alox = s01x ? 0 : 1, ahix = s01x ? n - 3 : n - 2;
-    const int aloy = s01y ? 0 : 1, ahiy = s01y ? n - 3 : n - 2;
-    const int aloz = s01z ? 0 : 1, ahiz = s01z ? n - 3 : n - 2;
-
-    int ax = f2i(floorf(rox)), ay = f2i(floorf(roy)), az = f2i(floorf(roz));
-    unsigned steps = 0;
-    H.hit = 0; H.capped = 0; H.block_id = 0; H.k = 0; H.sk = 0;
-    int      cur_cell = -1, cur_d = 0;
-    uint64_t cur_mask = 0;
-    bool     have_mask = false;
-    unsigned iters = 0;
-    for (;;) {
-        const int cpx = ax + s01x, cpy = ay + s01y, cpz = az + s01z;
-        if (!(lox < cpx && loy < cpy && loz < cpz && cpx < upx && cpy < upy && cpz < upz)) break;
-        if (steps >= P.max_steps) { H.capped = 1; break; }
-        iters += (cur_d > 0 && cur_cell >= 0) ? 1u : 0x10001u;  // diagnostic: high half counts unit steps
-        const int ux = ax - lox, uy = ay - loy, uz = az - loz;
-        if (cur_cell < 0) {  // first iteration: the start voxel's cell
-            int tx = ux + offx; tx -= tx >= n ? n : 0;
-            int ty = uy + offy; ty -= ty >= n ? n : 0;
-            int tz = uz + offz; tz -= tz >= n ? n : 0;
-            cur_cell  = ((tz >> 2) * nc + (ty >> 2)) * nc + (tx >> 2);
-            cur_d     = (int)P.cell_df[cur_cell];
-            have_mask = false;
-        }
-        // empty box around the anchor (window-relative voxel bounds, clipped to the anchors
-        // for which the loop test holds); a single voxel when the cell is not known empty
-        int blx = ux, bhx = ux, bly = uy, bhy = uy, blz = uz, bhz = uz;
-        const int d = cur_d;
-        if (d > 0 && steps + (unsigned)(24 * d) <= P.max_steps) {
-            const int r = d - 1;
-            blx = max(((ux >> 2) - r) * 4, alox); bhx = min(((ux >> 2) + r) * 4 + 3, ahix);
-            bly = max(((uy >> 2) - r) * 4, aloy); bhy = min(((uy >> 2) + r) * 4 + 3, ahiy);
-            blz = max(((uz >> 2) - r) * 4, aloz); bhz = min(((uz >> 2) + r) * 4 + 3, ahiz);
-        }
-        // exit planes (world coordinates) and their parameters
-        const int   ex = lox + (s01x ? bhx + 1 : blx), ey = loy + (s01y ? bhy + 1 : bly), ez = loz + (s01z ? bhz + 1 : blz);
-        const float tx = ((float)ex - rox) * invx, ty = ((float)ey - roy) * invy, tz = ((float)ez - roz) * invz;
-        const int   k  = argmin3(tx, ty, tz);
-        const float tk = k == 0 ? tx : (k == 1 ? ty : tz);
-        int nx = 0, ny = 0, nz = 0;
-        if (k == 0) nx = (s01x ? ex - cpx : cpx - ex) + 1;
-        if (k == 1) ny = (s01y ? ey - cpy : cpy - ey) + 1;
-        if (k == 2) nz = (s01z ? ez - cpz : cpz - ez) + 1;
-        if (bhx != blx || bhy != bly || bhz != blz) {
-            // axis j's events sort before the exit event of axis k on ties iff j < k
-            if (k != 0) nx = events_before(rox, rdx, invx, cpx, s11x, ax, lox + blx, lox + bhx, tk, true,
-                                           s01x ? lox + bhx - ax : ax - (lox + blx));
-            if (k != 1) ny = events_before(roy, rdy, invy, cpy, s11y, ay, loy + bly, loy + bhy, tk, k > 1,
-                                           s01y ? loy + bhy - ay : ay - (loy + bly));
-            if (k != 2) nz = events_before(roz, rdz, invz, cpz, s11z, az, loz + blz, loz + bhz, tk, false,
-                                           s01z ? loz + bhz - az : az - (loz + blz));
-        }
-        ax += s11x * nx; ay += s11y * ny; az += s11z * nz;
-        steps += (unsigned)(nx + ny + nz);
-        // test the voxel just entered
-        {
-            int qx = ax - lox + offx; qx -= qx >= n ? n : 0;
-            int qy = ay - loy + offy; qy -= qy >= n ? n : 0;
-            int qz = az - loz + offz; qz -= qz >= n ? n : 0;
-            const int cell = ((qz >> 2) * nc + (qy >> 2)) * nc + (qx >> 2);
-            if (cell != cur_cell) {
-                cur_cell  = cell;
-                cur_d     = (int)P.cell_df[cell];
-                have_mask = false;
-            }
-            if (cur_d == 0) {
-                if (!have_mask) { cur_mask = P.cell_mask[cell]; have_mask = true; }
-                const int bit = ((qz & 3) << 4) | ((qy & 3) << 2) | (qx & 3);
-                if ((cur_mask >> bit) & 1ull) {
-                    H.hit = 1; H.k = k; H.sk = k == 0 ? s11x : (k == 1 ? s11y : s11z);
-                    H.t = tk;
-                    H.hx = rox + rdx * tk; H.hy = roy + rdy * tk; H.hz = roz + rdz * tk;
-                    H.block_id = (unsigned)((const T *)P.block)[((size_t)qz * (size_t)n + (size_t)qy) * (size_t)n + (size_t)qx];
-                    break;
-                }
-            }
-        }
-    }
-    H.vx = ax; H.vy = ay; H.vz = az; H.steps = steps; H.iters = iters;
-    if (!H.hit) { H.t = -1.0f; H.hx = H.hy = H.hz = 0.0f; }
-}
-
-// ---------------------------------------------------------------------------
-// exact empty-space skipping, second form: cheaper iterations
-// ---------------------------------------------------------------------------
-// Same visit order as traverse_skip.  Differences:
-//  * works in window-relative anchors u = a - lower, so the loop test is one unsigned
-//    range compare per axis;
-//  * a step inside a non-empty cell is a plain unit step that reuses the cell's mask
-//    from registers and only recomputes the cell when the step leaves it;
-//  * the per-axis event count of a box exit comes from floor(ro + rd*t_exit) whenever that
-//    point is provably on the right side of every plane: the sign of t_j(i) - t_exit
-//    equals the sign of (i - pos_j)/rd_j as soon as |pos_j - i| exceeds
-//    u*(3|i - ro_j| + |rd_j t| + |pos_j|) with u = 2^-24 (three roundings in t_j(i), two in
-//    pos_j); the kernel uses the wider margin 2^-20*(|rd_j t| + |pos_j| + 1).  Within the
-//    margin only the nearest plane is in doubt and it is settled by comparing t_j(i) with
-//    t_exit directly, with the reference's tie rule.
+// its events that sort before the exit event.
+//
+// That count comes from floor(ro + rd*t_exit) whenever the exit point is provably on the
+// right side of every plane: the sign of t_j(i) - t_exit equals the sign of
+// (i - pos_j)/rd_j as soon as |pos_j - i| exceeds u*(3|i - ro_j| + |rd_j t| + |pos_j|) with
+// u = 2^-24 (three roundings in t_j(i), two in pos_j); the kernel uses the wider margin
+// 2^-20*(|rd_j t| + |pos_j| + 1).  Within the margin only the nearest plane is in doubt and
+// it is settled by comparing t_j(i) with t_exit directly, with the reference's tie rule.
+//
+// Empty boxes come from the cell records: for the ray's direction octant, distance d
+// means the d^3 cells that start at the current cell and extend in the ray's direction
+// are empty.  A step inside a non-empty cell is a plain unit step that tests the cell's
+// 64-bit mask from registers.  Anchors are kept window relative (u = a - lower), so the
+// loop test lower < a + s01 < upper is one unsigned range compare per axis.
 
 // New window-relative anchor on a non-exit axis after leaving the box at (tk, k).
 // Branch free: every lane evaluates the plane in doubt and selects.
@@ -286,11 +153,13 @@ VRT_DEV int axis_after_exit(float ro, float rd, float inv, int lo, int s01, int 
     return s01 ? max(un, u) : min(un, u);
 }
 
-template <typename T, bool OCT>
-VRT_DEV void traverse_skip2(const TraceParams &P, float rox, float roy, float roz, float rdx, float rdy,
-                            float rdz, int lox, int loy, int loz, int upx, int upy, int upz, RayHit &H)
+template <typename T>
+VRT_DEV void traverse_skip(const TraceParams &P, float rox, float roy, float roz, float rdx, float rdy,
+                           float rdz, int lox, int loy, int loz, int upx, int upy, int upz, RayHit &H)
 {
     const float invx = 1.0f / rdx, invy = 1.0f / rdy, invz = 1.0f / rdz;
+    // The box algebra needs finite, non-zero directions and finite plane parameters.
+    // Anything else takes the literal loop (NaN / inf semantics of the reference).
     const float big = 0x1.0p100f;
     const bool regular = (rdx != 0.0f) && (rdy != 0.0f) && (rdz != 0.0f) && (fabsf(invx) < big) &&
                          (fabsf(invy) < big) && (fabsf(invz) < big);
@@ -301,42 +170,47 @@ VRT_DEV void traverse_skip2(const TraceParams &P, float rox, float roy, float ro
     const int s01x = rdx > 0.0f ? 1 : 0, s01y = rdy > 0.0f ? 1 : 0, s01z = rdz > 0.0f ? 1 : 0;
     const int s11x = 2 * s01x - 1, s11y = 2 * s01y - 1, s11z = 2 * s01z - 1;
     const int n = P.n, nc = P.nc;
+    // texel of a window-relative anchor: u + off (mod n), off = rem_euclid(lower, n), a multiple of 4
     const int offx = rem_euclid(lox, n), offy = rem_euclid(loy, n), offz = rem_euclid(loz, n);
     // loop test lower < a + s01 < upper  <=>  alo <= u <= ahi
     const int alox = 1 - s01x, aloy = 1 - s01y, aloz = 1 - s01z;
-    const unsigned spanx = (unsigned)(n - 3), spany = spanx, spanz = spanx;  // ahi - alo
+    const unsigned span = (unsigned)(n - 3);  // ahi - alo
     const int ahix = alox + (n - 3), ahiy = aloy + (n - 3), ahiz = aloz + (n - 3);
     // world index of the next plane on each axis = u + pl
     const int plx = lox + s01x, ply = loy + s01y, plz = loz + s01z;
-
-    // OCT: the distance field of the ray's own octant -- distance d means the d^3 cells that
-    // start at the current cell and extend in the ray's direction are empty; otherwise the
-    // isotropic field -- the (2d-1)^3 cells centred on the current cell are empty.
-    const uint8_t *df = OCT ? P.cell_odf + (size_t)(s01x | (s01y << 1) | (s01z << 2)) * ((size_t)nc * nc * nc) : P.cell_df;
-    const int mlx = OCT ? 1 - s01x : 1, mhx = OCT ? s01x : 1;
-    const int mly = OCT ? 1 - s01y : 1, mhy = OCT ? s01y : 1;
-    const int mlz = OCT ? 1 - s01z : 1, mhz = OCT ? s01z : 1;
+    // byte of the record's distance word that belongs to this ray's octant
+    const int oct = s01x | (s01y << 1) | (s01z << 2);
+    const int dshift = 8 * (oct & 3);
+    const bool dhigh = oct >= 4;
+    // the box grows only forward: r cells on the side the ray moves to, none behind
+    const int mlx = 1 - s01x, mhx = s01x, mly = 1 - s01y, mhy = s01y, mlz = 1 - s01z, mhz = s01z;
 
     int ux = f2i_small(floorf(rox)) - lox, uy = f2i_small(floorf(roy)) - loy, uz = f2i_small(floorf(roz)) - loz;
     unsigned steps = 0, iters = 0;
     H.hit = 0; H.capped = 0; H.block_id = 0; H.k = 0; H.sk = 0;
     int      cur_cell = -1, d = 0;
     uint64_t cur_mask = 0;
-    bool     have_mask = false;
+    auto load_cell = [&](int cell) {
+        const uint4 r = P.cells[cell];
+        cur_cell = cell;
+        cur_mask = (uint64_t)r.x | ((uint64_t)r.y << 32);
+        d        = (int)(((dhigh ? r.w : r.z) >> dshift) & 0xffu);
+    };
+    auto cell_of = [&](int vx, int vy, int vz) {
+        int qx = vx + offx; qx -= qx >= n ? n : 0;
+        int qy = vy + offy; qy -= qy >= n ? n : 0;
+        int qz = vz + offz; qz -= qz >= n ? n : 0;
+        return ((qz >> 2) * nc + (qy >> 2)) * nc + (qx >> 2);
+    };
+    if ((unsigned)(ux - alox) <= span && (unsigned)(uy - aloy) <= span && (unsigned)(uz - aloz) <= span)
+        load_cell(cell_of(ux, uy, uz));  // the start voxel's cell (the voxel itself is never tested)
     for (;;) {
-        if ((unsigned)(ux - alox) > spanx || (unsigned)(uy - aloy) > spany || (unsigned)(uz - aloz) > spanz) break;
+        if ((unsigned)(ux - alox) > span || (unsigned)(uy - aloy) > span || (unsigned)(uz - aloz) > span) break;
         if (steps >= P.max_steps) { H.capped = 1; break; }
-        if (cur_cell < 0) {  // first iteration: the start voxel's cell (never tested for a hit)
-            int tx = ux + offx; tx -= tx >= n ? n : 0;
-            int ty = uy + offy; ty -= ty >= n ? n : 0;
-            int tz = uz + offz; tz -= tz >= n ? n : 0;
-            cur_cell = ((tz >> 2) * nc + (ty >> 2)) * nc + (tx >> 2);
-            d        = (int)df[cur_cell];
-        }
         int   k;
         float tk;
         bool  moved_cell;
-        if (d == 0 || steps + (unsigned)(24 * d) > P.max_steps) {
+        if (d == 0 || steps + (unsigned)(12 * d) > P.max_steps) {
             // unit step (raytrace.glsl:45-50 with a zero distance)
             iters += P.debug_iters == 2 ? 0u : 0x10001u;
             const float tx = ((float)(ux + plx) - rox) * invx;
@@ -373,18 +247,10 @@ VRT_DEV void traverse_skip2(const TraceParams &P, float rox, float roy, float ro
         }
         // test the voxel just entered
         if (moved_cell) {
-            int qx = ux + offx; qx -= qx >= n ? n : 0;
-            int qy = uy + offy; qy -= qy >= n ? n : 0;
-            int qz = uz + offz; qz -= qz >= n ? n : 0;
-            const int cell = ((qz >> 2) * nc + (qy >> 2)) * nc + (qx >> 2);
-            if (cell != cur_cell) {
-                cur_cell  = cell;
-                d         = (int)df[cell];
-                have_mask = false;
-            }
+            const int cell = cell_of(ux, uy, uz);
+            if (cell != cur_cell) load_cell(cell);
         }
         if (d == 0) {
-            if (!have_mask) { cur_mask = P.cell_mask[cur_cell]; have_mask = true; }
             const int bit = ((uz & 3) << 4) | ((uy & 3) << 2) | (ux & 3);  // off is a multiple of 4
             if ((cur_mask >> bit) & 1ull) {
                 H.hit = 1; H.k = k; H.sk = k == 0 ? s11x : (k == 1 ? s11y : s11z);
@@ -479,7 +345,7 @@ __global__ __launch_bounds__(256) void k_trace_literal(const TraceParams P)
     finish_pixel(P, gx, gy, (size_t)q * P.w + col, H);
 }
 
-template <typename T, int VARIANT>
+template <typename T>
 __global__ __launch_bounds__(256) void k_trace_skip(const TraceParams P)
 {
     unsigned col, q, row;
@@ -491,9 +357,7 @@ __global__ __launch_bounds__(256) void k_trace_skip(const TraceParams P)
     int lox, loy, loz, upx, upy, upz;
     loaded_area(P, rox, lox, upx); loaded_area(P, roy, loy, upy); loaded_area(P, roz, loz, upz);
     RayHit H;
-    if (VARIANT == 1) traverse_skip<T>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
-    else if (VARIANT == 2) traverse_skip2<T, false>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
-    else traverse_skip2<T, true>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
+    traverse_skip<T>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
     finish_pixel(P, gx, gy, (size_t)q * P.w + col, H);
 }
 
@@ -517,16 +381,8 @@ hipError_t launch_trace_skip(const TraceParams &p, int voxel_bytes, hipStream_t 
 {
     if (p.rows.rows == 0 || p.w == 0) return hipSuccess;
     const dim3 grid = trace_grid(p), block(256);
-    if (p.variant == 1) {  // first form of the skip traversal, kept for A/B measurements
-        if (voxel_bytes == 1) k_trace_skip<uint8_t, 1><<<grid, block, 0, s>>>(p);
-        else k_trace_skip<uint16_t, 1><<<grid, block, 0, s>>>(p);
-    } else if (p.variant == 2) {  // isotropic distance field
-        if (voxel_bytes == 1) k_trace_skip<uint8_t, 2><<<grid, block, 0, s>>>(p);
-        else k_trace_skip<uint16_t, 2><<<grid, block, 0, s>>>(p);
-    } else {
-        if (voxel_bytes == 1) k_trace_skip<uint8_t, 3><<<grid, block, 0, s>>>(p);
-        else k_trace_skip<uint16_t, 3><<<grid, block, 0, s>>>(p);
-    }
+    if (voxel_bytes == 1) k_trace_skip<uint8_t><<<grid, block, 0, s>>>(p);
+    else k_trace_skip<uint16_t><<<grid, block, 0, s>>>(p);
     return hipGetLastError();
 }
 

@@ -3,11 +3,10 @@
 //   k_terrain       : terrain_gen.comp:14-24 + noise.glsl:4-74 for a box of world voxels,
 //                     stored at their toroidal texels (bit-exact restatement: same
 //                     operation order as the shader, no FMA contraction).
-//   k_build_masks   : one 64-bit occupancy mask per 4^3 cell of the texel image.
-//   k_df_pass       : one axis of the separable (min, max) Chebyshev distance transform
-//                     over cells (torus metric): out(c) = min_r max(r, in(c +/- r)).
-//                     Three passes (x, y, z) from in = {0 non-empty, 255 empty} give the
-//                     distance, in cells, to the nearest non-empty cell, capped at 255.
+//   k_cell_masks    : one 64-bit occupancy mask per 4^3 cell of the texel image.
+//   k_df_dir_pass   : one axis of the separable (min, max) octant distance transform over
+//                     cells (torus metric); x, y, z passes per direction octant.
+//   k_pack_dist     : the eight octant distances of a cell into its 16-byte record.
 //   k_any_nonzero   : is the uploaded distance image all zero (as shipped)?
 #include "vrt_device.h"
 #include "vrt_kernels.h"
@@ -126,10 +125,11 @@ hipError_t launch_terrain(void *block, int voxel_bytes, int n, int x0, int y0, i
 }
 
 // ---------------------------------------------------------------------------
-// occupancy masks: cell (cx,cy,cz) covers texels [4c, 4c+4)^3, bit = z*16 + y*4 + x
+// cell records: cell (cx,cy,cz) covers texels [4c, 4c+4)^3
 // ---------------------------------------------------------------------------
+// occupancy mask, bit = z*16 + y*4 + x; the distance word is filled by k_pack_dist
 template <typename T>
-__global__ __launch_bounds__(256) void k_build_masks(const T *block, int n, int nc, uint64_t *cell_mask)
+__global__ __launch_bounds__(256) void k_cell_masks(const T *block, int n, int nc, uint4 *cells)
 {
     const int cx = blockIdx.x * 64 + (threadIdx.x & 63);
     const int cy = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -152,69 +152,16 @@ __global__ __launch_bounds__(256) void k_build_masks(const T *block, int n, int 
             m |= (uint64_t)bits << (z * 16 + y * 4);
         }
     }
-    cell_mask[((size_t)cz * nc + cy) * nc + cx] = m;
-}
-
-hipError_t launch_build_masks(const void *block, int voxel_bytes, int n, uint64_t *cell_mask, hipStream_t s)
-{
-    const int  nc = n / 4;
-    const dim3 grid((nc + 63) / 64, (nc + 3) / 4, nc), blockdim(256);
-    if (voxel_bytes == 1) k_build_masks<uint8_t><<<grid, blockdim, 0, s>>>((const uint8_t *)block, n, nc, cell_mask);
-    else k_build_masks<uint16_t><<<grid, blockdim, 0, s>>>((const uint16_t *)block, n, nc, cell_mask);
-    return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------
-// cell distance field
-// ---------------------------------------------------------------------------
-// FROM_MASK: in(c) = mask[c] != 0 ? 0 : 255, else in = previous pass.
-template <bool FROM_MASK>
-__global__ __launch_bounds__(256) void k_df_pass(const uint64_t *cell_mask, const uint8_t *in, uint8_t *out, int nc, int axis)
-{
-    const int cx = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int cy = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int cz = blockIdx.z;
-    if (cx >= nc || cy >= nc) return;
-    const size_t self = ((size_t)cz * nc + cy) * nc + cx;
-    auto value = [&](size_t i) -> int {
-        if (FROM_MASK) return cell_mask[i] != 0 ? 0 : 255;
-        return (int)in[i];
-    };
-    const int    pos    = axis == 0 ? cx : (axis == 1 ? cy : cz);
-    const size_t stride = axis == 0 ? 1 : (axis == 1 ? (size_t)nc : (size_t)nc * nc);
-    const size_t line   = self - (size_t)pos * stride;
-    int best = value(self);
-    // out = min over r of max(r, in(pos +/- r)); once r >= best nothing can improve
-    for (int r = 1; r < best; ++r) {
-        int p0 = pos - r; p0 += p0 < 0 ? nc : 0; p0 += p0 < 0 ? nc : 0;
-        int p1 = pos + r; p1 -= p1 >= nc ? nc : 0; p1 -= p1 >= nc ? nc : 0;
-        if (r >= nc) {  // more than one lap: every cell of the line has been seen
-            break;
-        }
-        const int v = min(value(line + (size_t)p0 * stride), value(line + (size_t)p1 * stride));
-        best = min(best, max(r, v));
-    }
-    out[self] = (uint8_t)best;
-}
-
-hipError_t launch_build_df(const uint64_t *cell_mask, int nc, uint8_t *df_a, uint8_t *df_b, hipStream_t s)
-{
-    // x pass: mask -> b ; y pass: b -> a ; z pass: a -> b ; result must end in df_a, so
-    // run x: mask -> a, y: a -> b, z: b -> a.
-    const dim3 grid((nc + 63) / 64, (nc + 3) / 4, nc), blockdim(256);
-    k_df_pass<true><<<grid, blockdim, 0, s>>>(cell_mask, nullptr, df_a, nc, 0);
-    k_df_pass<false><<<grid, blockdim, 0, s>>>(nullptr, df_a, df_b, nc, 1);
-    k_df_pass<false><<<grid, blockdim, 0, s>>>(nullptr, df_b, df_a, nc, 2);
-    return hipGetLastError();
+    cells[((size_t)cz * nc + cy) * nc + cx] = make_uint4((unsigned)m, (unsigned)(m >> 32), 0u, 0u);
 }
 
 // One axis of the octant transform: out(p) = min over r >= 0 of max(r, in(p + dir*r)) along
 // `axis` (torus).  Applied along x, y, z with directions (sx, sy, sz) to in = {0 non-empty,
 // 255 empty} it yields the Chebyshev distance to the nearest non-empty cell q with
 // s_k*(q_k - c_k) >= 0 on every axis, i.e. the side of the largest empty cube of cells that
-// has the cell at its corner and extends into that octant.
-template <bool FROM_MASK>
-__global__ __launch_bounds__(256) void k_df_dir_pass(const uint64_t *cell_mask, const uint8_t *in, uint8_t *out, int nc,
+// has the cell at its corner and extends into that octant (cap 255).
+template <bool FROM_CELLS>
+__global__ __launch_bounds__(256) void k_df_dir_pass(const uint4 *cells, const uint8_t *in, uint8_t *out, int nc,
                                                      int axis, int dir)
 {
     const int cx = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -223,7 +170,10 @@ __global__ __launch_bounds__(256) void k_df_dir_pass(const uint64_t *cell_mask, 
     if (cx >= nc || cy >= nc) return;
     const size_t self = ((size_t)cz * nc + cy) * nc + cx;
     auto value = [&](size_t i) -> int {
-        if (FROM_MASK) return cell_mask[i] != 0 ? 0 : 255;
+        if (FROM_CELLS) {
+            const uint2 m = *reinterpret_cast<const uint2 *>(cells + i);
+            return (m.x | m.y) != 0 ? 0 : 255;
+        }
         return (int)in[i];
     };
     const int    pos    = axis == 0 ? cx : (axis == 1 ? cy : cz);
@@ -239,21 +189,40 @@ __global__ __launch_bounds__(256) void k_df_dir_pass(const uint64_t *cell_mask, 
     out[self] = (uint8_t)best;
 }
 
-hipError_t launch_build_octant_df(const uint64_t *cell_mask, int nc, uint8_t *odf, uint8_t *tmp, hipStream_t s)
+// gather the eight octant fields into the distance word of each record
+__global__ __launch_bounds__(256) void k_pack_dist(const uint8_t *oct, size_t ncells, uint4 *cells)
 {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= ncells) return;
+    unsigned lo = 0, hi = 0;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        lo |= (unsigned)oct[(size_t)o * ncells + i] << (8 * o);
+        hi |= (unsigned)oct[(size_t)(o + 4) * ncells + i] << (8 * o);
+    }
+    uint2 *dst = reinterpret_cast<uint2 *>(cells + i) + 1;
+    *dst = make_uint2(lo, hi);
+}
+
+hipError_t launch_build_cells(const void *block, int voxel_bytes, int n, uint4 *cells, uint8_t *tmp, hipStream_t s)
+{
+    const int    nc = n / 4;
     const dim3   grid((nc + 63) / 64, (nc + 3) / 4, nc), blockdim(256);
-    const size_t cells = (size_t)nc * nc * nc;
-    uint8_t *tx = tmp, *ty0 = tmp + cells, *ty1 = tmp + 2 * cells;
+    const size_t ncells = (size_t)nc * nc * nc;
+    if (voxel_bytes == 1) k_cell_masks<uint8_t><<<grid, blockdim, 0, s>>>((const uint8_t *)block, n, nc, cells);
+    else k_cell_masks<uint16_t><<<grid, blockdim, 0, s>>>((const uint16_t *)block, n, nc, cells);
+    uint8_t *tx = tmp, *ty0 = tmp + ncells, *ty1 = tmp + 2 * ncells, *oct = tmp + 3 * ncells;
     for (int sx = 0; sx < 2; ++sx) {
-        k_df_dir_pass<true><<<grid, blockdim, 0, s>>>(cell_mask, nullptr, tx, nc, 0, sx ? 1 : -1);
+        k_df_dir_pass<true><<<grid, blockdim, 0, s>>>(cells, nullptr, tx, nc, 0, sx ? 1 : -1);
         k_df_dir_pass<false><<<grid, blockdim, 0, s>>>(nullptr, tx, ty0, nc, 1, -1);
         k_df_dir_pass<false><<<grid, blockdim, 0, s>>>(nullptr, tx, ty1, nc, 1, 1);
         for (int sy = 0; sy < 2; ++sy)
             for (int sz = 0; sz < 2; ++sz)
                 k_df_dir_pass<false><<<grid, blockdim, 0, s>>>(nullptr, sy ? ty1 : ty0,
-                                                               odf + (size_t)(sx | (sy << 1) | (sz << 2)) * cells, nc, 2,
+                                                               oct + (size_t)(sx | (sy << 1) | (sz << 2)) * ncells, nc, 2,
                                                                sz ? 1 : -1);
     }
+    k_pack_dist<<<(unsigned)((ncells + 255) / 256), 256, 0, s>>>(oct, ncells, cells);
     return hipGetLastError();
 }
 

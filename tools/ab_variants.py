@@ -8,7 +8,7 @@ import numpy as np
 import torch
 from raytracing_amd import GraphicsCore, VOXEL_PACKED_U8, TRACE_SKIP, TRACE_LITERAL, scenes
 
-variants = [v for v in (sys.argv[1] if len(sys.argv) > 1 else "1,2").split(",")]
+variants = [v for v in (sys.argv[1] if len(sys.argv) > 1 else "0").split(",")]
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 W, H, N = 1920, 1080, 1024
 p = scenes.pose_headline()

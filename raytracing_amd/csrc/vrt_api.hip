@@ -53,6 +53,8 @@ struct vrt_ctx {
     bool        have_world   = false;
     // skip structure
     uint4      *d_cells      = nullptr;  // (n/4)^3 records: occupancy mask + octant distances
+    uint16_t   *d_tops       = nullptr;  // column-top pyramid scratch, 2 * (n/4)^2
+    int         pyr_offcy    = -1;       // vertical window offset (cells) the pyramid entries were built for
     bool        skip_valid   = false;
     uint32_t   *d_flag       = nullptr;
     // staging for host-resident outputs
@@ -84,20 +86,38 @@ int drain_events(vrt_ctx *c)
     return VRT_OK;
 }
 
-int ensure_skip_structure(vrt_ctx *c)
+// offcy: rem_euclid(lower_y, n) / 4 of the window the next trace uses
+int ensure_skip_structure(vrt_ctx *c, int offcy)
 {
-    if (c->skip_valid) return VRT_OK;
-    if (!c->d_cells) HIP_TRY(hipMalloc(&c->d_cells, cells(c) * sizeof(uint4)));
-    // scratch for the separable distance passes: released again, the build is not a hot path
-    uint8_t *tmp = nullptr;
-    HIP_TRY(hipMalloc(&tmp, 11 * cells(c)));
-    hipError_t e = vrt::launch_build_cells(c->d_block, c->voxel_bytes, (int)c->n, c->d_cells, tmp, c->stream);
-    hipError_t e2 = hipStreamSynchronize(c->stream);
-    (void)hipFree(tmp);
-    HIP_TRY(e);
-    HIP_TRY(e2);
-    c->skip_valid = true;
+    if (!c->skip_valid) {
+        if (!c->d_cells) HIP_TRY(hipMalloc(&c->d_cells, cells(c) * sizeof(uint4)));
+        if (!c->d_tops) HIP_TRY(hipMalloc(&c->d_tops, 2 * (size_t)(c->n / 4) * (c->n / 4) * sizeof(uint16_t)));
+        // scratch for the separable distance passes: released again, the build is not a hot path
+        uint8_t *tmp = nullptr;
+        HIP_TRY(hipMalloc(&tmp, 11 * cells(c)));
+        hipError_t e = vrt::launch_build_cells(c->d_block, c->voxel_bytes, (int)c->n, c->d_cells, tmp, c->stream);
+        hipError_t e2 = hipStreamSynchronize(c->stream);
+        (void)hipFree(tmp);
+        HIP_TRY(e);
+        HIP_TRY(e2);
+        c->skip_valid = true;
+        c->pyr_offcy = -1;
+    }
+    if (c->pyr_offcy != offcy) {
+        HIP_TRY(vrt::launch_build_pyramid(c->d_cells, (int)c->n / 4, offcy, c->d_tops, c->stream));
+        c->pyr_offcy = offcy;
+    }
     return VRT_OK;
+}
+
+// vertical offset (in cells) of the loaded window for a camera at height y (raytrace.glsl:19-24)
+int window_offcy(const vrt_ctx *c, float y)
+{
+    const int n = (int)c->n;
+    const int lower = (int)std::floor(y / (float)VRT_CHUNK_SIZE) * VRT_CHUNK_SIZE + VRT_CHUNK_SIZE / 2 - n / 2;
+    int r = lower % n;
+    if (r < 0) r += n;
+    return r / 4;
 }
 
 struct Plane { size_t off, bytes; void *host; };
@@ -125,7 +145,7 @@ int do_trace(vrt_ctx *c, const float *cam, uint32_t w, uint32_t h, const vrt::Ro
         default: use_skip = !c->dist_nonzero; break;
     }
     if (use_skip) {
-        int rc = ensure_skip_structure(c);
+        int rc = ensure_skip_structure(c, window_offcy(c, cam[13]));
         if (rc != VRT_OK) return rc;
     }
 
@@ -236,7 +256,7 @@ int vrt_destroy(vrt_ctx *c)
         if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]);
         if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]);
     }
-    void *bufs[] = {c->d_block, c->d_dist, c->d_cells, c->d_flag, c->d_stage};
+    void *bufs[] = {c->d_block, c->d_dist, c->d_cells, c->d_tops, c->d_flag, c->d_stage};
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -305,7 +325,7 @@ int vrt_reset_distance_field(vrt_ctx *c)
     c->dist_nonzero = false;
     if (c->have_world && c->trace_mode != VRT_TRACE_LITERAL) {
         c->skip_valid = false;
-        return ensure_skip_structure(c);
+        return ensure_skip_structure(c, c->pyr_offcy >= 0 ? c->pyr_offcy : 0);
     }
     return VRT_OK;
 }

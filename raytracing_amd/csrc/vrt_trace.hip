@@ -126,32 +126,24 @@ VRT_DEV void traverse_literal(const TraceParams &P, float rox, float roy, float 
 // (i - pos_j)/rd_j as soon as |pos_j - i| exceeds u*(3|i - ro_j| + |rd_j t| + |pos_j|) with
 // u = 2^-24 (three roundings in t_j(i), two in pos_j); the kernel uses the wider margin
 // 2^-20*(|rd_j t| + |pos_j| + 1).  Within the margin only the nearest plane is in doubt and
-// it is settled by comparing t_j(i) with t_exit directly, with the reference's tie rule.
+// it is settled by comparing t_j(i) with t_exit directly, with the reference's tie rule
+// (rare: taken by a wavefront only when one of its lanes is that close to a plane).
 //
-// Empty boxes come from the cell records: for the ray's direction octant, distance d
-// means the d^3 cells that start at the current cell and extend in the ray's direction
-// are empty.  A step inside a non-empty cell is a plain unit step that tests the cell's
-// 64-bit mask from registers.  Anchors are kept window relative (u = a - lower), so the
-// loop test lower < a + s01 < upper is one unsigned range compare per axis.
-
-// New window-relative anchor on a non-exit axis after leaving the box at (tk, k).
-// Branch free: every lane evaluates the plane in doubt and selects.
-VRT_DEV int axis_after_exit(float ro, float rd, float inv, int lo, int s01, int u, int bl, int bh, float tk,
-                            bool inclusive)
-{
-    const float rt   = rd * tk;
-    const float pos  = ro + rt;
-    const float i0   = rintf(pos);
-    const float eps  = 0x1.0p-20f * ((fabsf(rt) + fabsf(pos)) + 1.0f);
-    const float tt   = (i0 - ro) * inv;  // t_j of the nearest plane, as the reference computes it
-    const bool  crossed = inclusive ? tt <= tk : tt < tk;
-    const int   a_near  = f2i_small(i0) - ((crossed != (s01 != 0)) ? 1 : 0);
-    const int   a_far   = f2i_small(floorf(pos));
-    const int   a       = fabsf(pos - i0) <= eps ? a_near : a_far;
-    int un = a - lo;
-    un = min(max(un, bl), bh);
-    return s01 ? max(un, u) : min(un, u);
-}
+// Direction-normalised coordinates.  Per axis the kernel works in a mirrored frame in
+// which the ray always moves towards +: ro' = s*ro, rd' = |rd|, inv' = |inv| and the
+// window-relative anchor u = a - lower becomes w = u (s > 0) or ~u = -u-1 (s < 0).  Voxel w
+// spans [w + ln, w + ln + 1] in the mirrored frame (ln = s*lower), the next plane is
+// w + ln + 1, a unit step is w += 1 and a cell boundary is crossed when (w & 3) == 0.
+// Negation is exact in IEEE arithmetic and commutes with every rounding, so
+// ((float)P' - ro') * inv' has the bits of the reference's ((float)P - ro) * inv -- except for
+// the sign of an exact zero, which no comparison sees; the reported t is recomputed in the
+// original frame.
+//
+// Empty boxes come from the cell records (vrt_kernels.h): the octant distance d says the
+// d^3 cells that start at the current cell and extend in the ray's direction are empty;
+// for empty cells the record also names the largest aligned block of cell columns whose
+// occupied layers all lie below the cell (the column-top pyramid), which gives a box as
+// wide as that block and as high as the window.
 
 template <typename T>
 VRT_DEV void traverse_skip(const TraceParams &P, float rox, float roy, float roz, float rdx, float rdy,
@@ -167,104 +159,142 @@ VRT_DEV void traverse_skip(const TraceParams &P, float rox, float roy, float roz
         traverse_literal<T, false>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
         return;
     }
-    const int s01x = rdx > 0.0f ? 1 : 0, s01y = rdy > 0.0f ? 1 : 0, s01z = rdz > 0.0f ? 1 : 0;
-    const int s11x = 2 * s01x - 1, s11y = 2 * s01y - 1, s11z = 2 * s01z - 1;
     const int n = P.n, nc = P.nc;
-    // texel of a window-relative anchor: u + off (mod n), off = rem_euclid(lower, n), a multiple of 4
-    const int offx = rem_euclid(lox, n), offy = rem_euclid(loy, n), offz = rem_euclid(loz, n);
-    // loop test lower < a + s01 < upper  <=>  alo <= u <= ahi
-    const int alox = 1 - s01x, aloy = 1 - s01y, aloz = 1 - s01z;
-    const unsigned span = (unsigned)(n - 3);  // ahi - alo
-    const int ahix = alox + (n - 3), ahiy = aloy + (n - 3), ahiz = aloz + (n - 3);
-    // world index of the next plane on each axis = u + pl
-    const int plx = lox + s01x, ply = loy + s01y, plz = loz + s01z;
+    const bool px = rdx > 0.0f, py = rdy > 0.0f, pz = rdz > 0.0f;
+    const int  smx = px ? 0 : -1, smy = py ? 0 : -1, smz = pz ? 0 : -1;            // u = w ^ sm
+    const float rnx = px ? rox : -rox, rny = py ? roy : -roy, rnz = pz ? roz : -roz;  // mirrored origin
+    const float dnx = fabsf(rdx), dny = fabsf(rdy), dnz = fabsf(rdz);
+    const float inx = fabsf(invx), iny = fabsf(invy), inz = fabsf(invz);
+    const int  lnx = px ? lox : -lox, lny = py ? loy : -loy, lnz = pz ? loz : -loz;
+    // loop test lower < a + s01 < upper  <=>  wlo <= w <= wlo + n - 3
+    const int  wlox = px ? 0 : 1 - n, wloy = py ? 0 : 1 - n, wloz = pz ? 0 : 1 - n;
+    const int  whix = wlox + (n - 3), whiy = wloy + (n - 3), whiz = wloz + (n - 3);
+    const unsigned span = (unsigned)(n - 3);
+    // texel of an anchor: u + off (mod n), off = rem_euclid(lower, n), a multiple of 4
+    const int  offx = rem_euclid(lox, n), offy = rem_euclid(loy, n), offz = rem_euclid(loz, n);
     // byte of the record's distance word that belongs to this ray's octant
-    const int oct = s01x | (s01y << 1) | (s01z << 2);
-    const int dshift = 8 * (oct & 3);
+    const int  oct = (px ? 1 : 0) | (py ? 2 : 0) | (pz ? 4 : 0);
+    const int  dshift = 8 * (oct & 3);
     const bool dhigh = oct >= 4;
-    // the box grows only forward: r cells on the side the ray moves to, none behind
-    const int mlx = 1 - s01x, mhx = s01x, mly = 1 - s01y, mhy = s01y, mlz = 1 - s01z, mhz = s01z;
 
-    int ux = f2i_small(floorf(rox)) - lox, uy = f2i_small(floorf(roy)) - loy, uz = f2i_small(floorf(roz)) - loz;
+    int wx = (f2i_small(floorf(rox)) - lox) ^ smx;
+    int wy = (f2i_small(floorf(roy)) - loy) ^ smy;
+    int wz = (f2i_small(floorf(roz)) - loz) ^ smz;
     unsigned steps = 0, iters = 0;
     H.hit = 0; H.capped = 0; H.block_id = 0; H.k = 0; H.sk = 0;
     int      cur_cell = -1, d = 0;
-    uint64_t cur_mask = 0;
-    auto load_cell = [&](int cell) {
-        const uint4 r = P.cells[cell];
-        cur_cell = cell;
-        cur_mask = (uint64_t)r.x | ((uint64_t)r.y << 32);
-        d        = (int)(((dhigh ? r.w : r.z) >> dshift) & 0xffu);
+    unsigned info = 0;       // empty cells: column-top pyramid entry (level | layers << 8)
+    uint64_t cur_mask = 0;   // non-empty cells: occupancy
+    int qx = 0, qy = 0, qz = 0;  // texel of the anchor at the last cell lookup
+    auto locate = [&]() {
+        qx = (wx ^ smx) + offx; qx -= qx >= n ? n : 0;
+        qy = (wy ^ smy) + offy; qy -= qy >= n ? n : 0;
+        qz = (wz ^ smz) + offz; qz -= qz >= n ? n : 0;
+        const int cell = ((qz >> 2) * nc + (qy >> 2)) * nc + (qx >> 2);
+        if (cell != cur_cell) {
+            const uint4 r = P.cells[cell];
+            cur_cell = cell;
+            info     = r.x;
+            cur_mask = (uint64_t)r.x | ((uint64_t)r.y << 32);
+            d        = (int)(((dhigh ? r.w : r.z) >> dshift) & 0xffu);
+        }
     };
-    auto cell_of = [&](int vx, int vy, int vz) {
-        int qx = vx + offx; qx -= qx >= n ? n : 0;
-        int qy = vy + offy; qy -= qy >= n ? n : 0;
-        int qz = vz + offz; qz -= qz >= n ? n : 0;
-        return ((qz >> 2) * nc + (qy >> 2)) * nc + (qx >> 2);
-    };
-    if ((unsigned)(ux - alox) <= span && (unsigned)(uy - aloy) <= span && (unsigned)(uz - aloz) <= span)
-        load_cell(cell_of(ux, uy, uz));  // the start voxel's cell (the voxel itself is never tested)
+    if ((unsigned)(wx - wlox) <= span && (unsigned)(wy - wloy) <= span && (unsigned)(wz - wloz) <= span)
+        locate();  // the start voxel's cell (the voxel itself is never tested)
     for (;;) {
-        if ((unsigned)(ux - alox) > span || (unsigned)(uy - aloy) > span || (unsigned)(uz - aloz) > span) break;
+        if ((unsigned)(wx - wlox) > span || (unsigned)(wy - wloy) > span || (unsigned)(wz - wloz) > span) break;
         if (steps >= P.max_steps) { H.capped = 1; break; }
         int   k;
         float tk;
         bool  moved_cell;
-        if (d == 0 || steps + (unsigned)(12 * d) > P.max_steps) {
+        bool  unit = d == 0;
+        int   fwx = wx, fwy = wy, fwz = wz;  // last anchor of the empty box on each axis
+        if (!unit) {
+            const int lvl = (int)(info & 0xffu);
+            if (lvl > 0 && (1 << lvl) > d) {
+                // column-top pyramid: the aligned block of 2^lvl x 2^lvl cell columns around this
+                // one is empty from layer (info >> 8) up to the top of the window
+                const int m4 = (4 << lvl) - 1;
+                locate();  // texel of the current anchor (a no-op load: the cell is unchanged)
+                fwx = min(wx + ((qx ^ ~smx) & m4), whix);
+                fwz = min(wz + ((qz ^ ~smz) & m4), whiz);
+                fwy = py ? whiy : min(~(int)((info >> 8) << 2), whiy);
+            } else {
+                const int r4 = (d - 1) << 2;
+                fwx = min((wx | 3) + r4, whix);
+                fwy = min((wy | 3) + r4, whiy);
+                fwz = min((wz | 3) + r4, whiz);
+            }
+            // the box may not carry the ray past the step cap (only with tiny caps)
+            unit = steps + (unsigned)((fwx - wx) + (fwy - wy) + (fwz - wz) + 3) > P.max_steps;
+        }
+        if (unit) {
             // unit step (raytrace.glsl:45-50 with a zero distance)
             iters += P.debug_iters == 2 ? 0u : 0x10001u;
-            const float tx = ((float)(ux + plx) - rox) * invx;
-            const float ty = ((float)(uy + ply) - roy) * invy;
-            const float tz = ((float)(uz + plz) - roz) * invz;
+            const float tx = ((float)(wx + lnx + 1) - rnx) * inx;
+            const float ty = ((float)(wy + lny + 1) - rny) * iny;
+            const float tz = ((float)(wz + lnz + 1) - rnz) * inz;
             k  = argmin3(tx, ty, tz);
             tk = k == 0 ? tx : (k == 1 ? ty : tz);
-            const int oldu = k == 0 ? ux : (k == 1 ? uy : uz);
-            const int newu = oldu + (k == 0 ? s11x : (k == 1 ? s11y : s11z));
-            ux = k == 0 ? newu : ux; uy = k == 1 ? newu : uy; uz = k == 2 ? newu : uz;
-            moved_cell = ((oldu ^ newu) & ~3) != 0;
+            wx += k == 0 ? 1 : 0; wy += k == 1 ? 1 : 0; wz += k == 2 ? 1 : 0;
+            const int wk = k == 0 ? wx : (k == 1 ? wy : wz);
+            moved_cell = (wk & 3) == 0;
             steps += 1;
         } else {
             iters += P.debug_iters == 2 ? (d == 1 ? 1u : (d == 2 ? 0x100u : (d <= 4 ? 0x10000u : 0x1000000u))) : 1u;
-            const int r = d - 1;
-            const int blx = max(((ux >> 2) - r * mlx) * 4, alox), bhx = min(((ux >> 2) + r * mhx) * 4 + 3, ahix);
-            const int bly = max(((uy >> 2) - r * mly) * 4, aloy), bhy = min(((uy >> 2) + r * mhy) * 4 + 3, ahiy);
-            const int blz = max(((uz >> 2) - r * mlz) * 4, aloz), bhz = min(((uz >> 2) + r * mhz) * 4 + 3, ahiz);
-            // first anchor outside the box on each axis, and the plane crossed to get there
-            const int nux = s01x ? bhx + 1 : blx - 1, nuy = s01y ? bhy + 1 : bly - 1, nuz = s01z ? bhz + 1 : blz - 1;
-            const float tx = ((float)(nux + (lox + 1 - s01x)) - rox) * invx;
-            const float ty = ((float)(nuy + (loy + 1 - s01y)) - roy) * invy;
-            const float tz = ((float)(nuz + (loz + 1 - s01z)) - roz) * invz;
+            // exit planes = lower faces of the first anchors outside the box
+            const float tx = ((float)(fwx + lnx + 1) - rnx) * inx;
+            const float ty = ((float)(fwy + lny + 1) - rny) * iny;
+            const float tz = ((float)(fwz + lnz + 1) - rnz) * inz;
             k  = argmin3(tx, ty, tz);
             tk = k == 0 ? tx : (k == 1 ? ty : tz);
-            // axis j's events sort before the exit event of axis k on ties iff j < k
-            const int wx = axis_after_exit(rox, rdx, invx, lox, s01x, ux, blx, bhx, tk, true);
-            const int wy = axis_after_exit(roy, rdy, invy, loy, s01y, uy, bly, bhy, tk, k == 2);
-            const int wz = axis_after_exit(roz, rdz, invz, loz, s01z, uz, blz, bhz, tk, false);
-            const int vx = k == 0 ? nux : wx, vy = k == 1 ? nuy : wy, vz = k == 2 ? nuz : wz;
-            steps += (unsigned)(abs(vx - ux) + abs(vy - uy) + abs(vz - uz));
-            ux = vx; uy = vy; uz = vz;
+            // anchors at the exit from the exit point, where it is clear of every plane
+            const float rtx = dnx * tk, rty = dny * tk, rtz = dnz * tk;
+            const float psx = rnx + rtx, psy = rny + rty, psz = rnz + rtz;
+            const float i0x = rintf(psx), i0y = rintf(psy), i0z = rintf(psz);
+            int vx = f2i_small(floorf(psx)) - lnx, vy = f2i_small(floorf(psy)) - lny, vz = f2i_small(floorf(psz)) - lnz;
+            const bool nearx = fabsf(psx - i0x) <= 0x1.0p-20f * ((rtx + fabsf(psx)) + 1.0f);
+            const bool neary = fabsf(psy - i0y) <= 0x1.0p-20f * ((rty + fabsf(psy)) + 1.0f);
+            const bool nearz = fabsf(psz - i0z) <= 0x1.0p-20f * ((rtz + fabsf(psz)) + 1.0f);
+            if (__any((nearx || neary || nearz) ? 1 : 0)) {
+                // a plane within the margin: has the reference crossed it before the exit event?
+                // axis j's events sort before the exit event of axis k on ties iff j < k
+                const float ttx = (i0x - rnx) * inx, tty = (i0y - rny) * iny, ttz = (i0z - rnz) * inz;
+                const bool  cx = ttx <= tk;
+                const bool  cy = k == 2 ? tty <= tk : tty < tk;
+                const bool  cz = ttz < tk;
+                vx = nearx ? f2i_small(i0x) - lnx - (cx ? 0 : 1) : vx;
+                vy = neary ? f2i_small(i0y) - lny - (cy ? 0 : 1) : vy;
+                vz = nearz ? f2i_small(i0z) - lnz - (cz ? 0 : 1) : vz;
+            }
+            vx = k == 0 ? fwx + 1 : min(max(vx, wx), fwx);
+            vy = k == 1 ? fwy + 1 : min(max(vy, wy), fwy);
+            vz = k == 2 ? fwz + 1 : min(max(vz, wz), fwz);
+            steps += (unsigned)((vx - wx) + (vy - wy) + (vz - wz));
+            wx = vx; wy = vy; wz = vz;
             moved_cell = true;
         }
         // test the voxel just entered
-        if (moved_cell) {
-            const int cell = cell_of(ux, uy, uz);
-            if (cell != cur_cell) load_cell(cell);
-        }
+        if (moved_cell) locate();
         if (d == 0) {
-            const int bit = ((uz & 3) << 4) | ((uy & 3) << 2) | (ux & 3);  // off is a multiple of 4
+            const int bit = (((wz ^ smz) & 3) << 4) | (((wy ^ smy) & 3) << 2) | ((wx ^ smx) & 3);
             if ((cur_mask >> bit) & 1ull) {
-                H.hit = 1; H.k = k; H.sk = k == 0 ? s11x : (k == 1 ? s11y : s11z);
-                H.t = tk;
-                H.hx = rox + rdx * tk; H.hy = roy + rdy * tk; H.hz = roz + rdz * tk;
-                int qx = ux + offx; qx -= qx >= n ? n : 0;
-                int qy = uy + offy; qy -= qy >= n ? n : 0;
-                int qz = uz + offz; qz -= qz >= n ? n : 0;
+                H.hit = 1; H.k = k; H.sk = k == 0 ? (px ? 1 : -1) : (k == 1 ? (py ? 1 : -1) : (pz ? 1 : -1));
+                // t as the reference computes it, in the unmirrored frame: the mirrored value has the
+                // same bits except for the sign of an exact zero ((x - x) is +0 in either frame)
+                const int   pk = k == 0 ? (wx ^ smx) + lox + (px ? 0 : 1)
+                               : (k == 1 ? (wy ^ smy) + loy + (py ? 0 : 1) : (wz ^ smz) + loz + (pz ? 0 : 1));
+                const float th = ((float)pk - (k == 0 ? rox : (k == 1 ? roy : roz))) * (k == 0 ? invx : (k == 1 ? invy : invz));
+                H.t = th;
+                H.hx = rox + rdx * th; H.hy = roy + rdy * th; H.hz = roz + rdz * th;
+                locate();
                 H.block_id = (unsigned)((const T *)P.block)[((size_t)qz * (size_t)n + (size_t)qy) * (size_t)n + (size_t)qx];
                 break;
             }
         }
     }
-    H.vx = ux + lox; H.vy = uy + loy; H.vz = uz + loz; H.steps = steps; H.iters = iters;
+    H.vx = (wx ^ smx) + lox; H.vy = (wy ^ smy) + loy; H.vz = (wz ^ smz) + loz;
+    H.steps = steps; H.iters = iters;
     if (!H.hit) { H.t = -1.0f; H.hx = H.hy = H.hz = 0.0f; }
 }
 

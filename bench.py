@@ -47,13 +47,13 @@ def rank_pose(rank, world):
 
 
 def cpu_baseline(core, cam, steps_plane):
-    """Oracle on every 4th 16-row strip of the frame (about a quarter of the rays)."""
+    """Oracle on the whole frame, strip by strip (about 30 CPU-seconds on 16 threads)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     block = core.download_world()
     world = O.World(block)
     threads = O.host_threads()
-    strips = list(range(0, H // 16, 4))
+    strips = list(range(0, (H + 15) // 16))
     rays = 0
     t0 = time.perf_counter()
     ok = True
@@ -63,7 +63,7 @@ def cpu_baseline(core, cam, steps_plane):
         ok = ok and np.array_equal(out["steps"], steps_plane[s * 16:s * 16 + 16])
     dt = time.perf_counter() - t0
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"{len(strips)} of {H // 16} 16-row strips of the same 1080p frame ({rays} rays, {dt:.1f} s)",
+            "sample": f"the same 1080p frame, all {len(strips)} 16-row strips ({rays} rays, {dt:.1f} s wall)",
             "matches_gpu_steps": bool(ok)}
 
 

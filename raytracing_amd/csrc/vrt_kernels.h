@@ -24,7 +24,7 @@ struct TraceParams {
     int32_t  n;            // voxels per axis
     int32_t  n_pow2_mask;  // n-1 if n is a power of two, else -1
     uint32_t max_steps;
-    uint32_t variant;      // skip-kernel form (A/B measurements); 0 = default
+    uint32_t variant;      // selects an experimental kernel form in A/B measurements; 0 = default
     uint32_t debug_iters;  // diagnostic: the steps plane receives the kernel's own loop count
     // world
     const void     *block;  // n^3 texels (u8 or u16), linear x fastest

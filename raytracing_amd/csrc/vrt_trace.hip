@@ -230,7 +230,7 @@ VRT_DEV void traverse_skip(const TraceParams &P, float rox, float roy, float roz
         }
         if (unit) {
             // unit step (raytrace.glsl:45-50 with a zero distance)
-            iters += P.debug_iters == 2 ? 0u : 0x10001u;
+            iters += 0x10001u;  // diagnostic: high half counts unit steps
             const float tx = ((float)(wx + lnx + 1) - rnx) * inx;
             const float ty = ((float)(wy + lny + 1) - rny) * iny;
             const float tz = ((float)(wz + lnz + 1) - rnz) * inz;
@@ -241,7 +241,7 @@ VRT_DEV void traverse_skip(const TraceParams &P, float rox, float roy, float roz
             moved_cell = (wk & 3) == 0;
             steps += 1;
         } else {
-            iters += P.debug_iters == 2 ? (d == 1 ? 1u : (d == 2 ? 0x100u : (d <= 4 ? 0x10000u : 0x1000000u))) : 1u;
+            iters += 1u;
             // exit planes = lower faces of the first anchors outside the box
             const float tx = ((float)(fwx + lnx + 1) - rnx) * inx;
             const float ty = ((float)(fwy + lny + 1) - rny) * iny;

@@ -109,6 +109,22 @@ int vrt_reset_distance_field(vrt_ctx *ctx);
 int vrt_trace(vrt_ctx *ctx, const float cam_col_major[16], uint32_t w, uint32_t h,
               uint32_t y0, uint32_t y1, const vrt_outputs *out);
 
+/* Secondary rays per primary hit: one shadow ray towards normalize(0.4, 0.8, 0.45) and four
+ * cosine-distributed ambient-occlusion rays about the face normal (hash chain
+ * pcg(0x5EED ^ (row*w + col))), origin hit_point + normal*1e-3, traced by the skip kernel in
+ * the camera's loaded area.  NO counterpart in the reference (its shader casts primary rays
+ * only); an incoherent-ray stress workload whose exact statement is the CPU oracle's.
+ * Needs an all-zero distance image.  Planes cover rows [y0,y1); any pointer may be NULL. */
+typedef struct vrt_secondary_outputs {
+    uint32_t struct_size;   /* sizeof(vrt_secondary_outputs) */
+    uint32_t memory;        /* VRT_MEM_HOST or VRT_MEM_DEVICE */
+    uint8_t  *shadow;       /* 1 if the shadow ray hits; 0 otherwise and for primary misses */
+    uint8_t  *ao;           /* number of ambient-occlusion rays that hit, 0..4 */
+    uint32_t *sec_steps;    /* loop iterations summed over the five secondary rays */
+} vrt_secondary_outputs;
+int vrt_trace_secondary(vrt_ctx *ctx, const float cam_col_major[16], uint32_t w, uint32_t h,
+                        uint32_t y0, uint32_t y1, const vrt_secondary_outputs *out);
+
 /* Rows of interleaved strips for multi-GPU sharding: strip s (rows [s*strip_h, (s+1)*strip_h))
  * belongs to part s % parts; traces the strips of `part`, packed in strip order, so plane
  * element index = (packed_row)*w + c.  vrt_strip_rows gives the packed row count. */

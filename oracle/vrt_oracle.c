@@ -146,11 +146,17 @@ static inline int inside_loaded_area(const int32_t pos[3], const int32_t lower[3
 
 void orc_trace_ray(const orc_world *wd, const float ro[3], const float rd[3], orc_ray *out)
 {
+    orc_trace_ray_from(wd, ro, ro, rd, out); /* raytrace.glsl:16,123: ro = player_position */
+}
+
+void orc_trace_ray_from(const orc_world *wd, const float player_position[3], const float ro[3],
+                        const float rd[3], orc_ray *out)
+{
     float   inv_rd[3];
     int32_t s01[3], s11[3], anchor[3], cp[3], lower[3], upper[3];
     memset(out, 0, sizeof *out);
 
-    loaded_area_bounds(ro, wd->n, lower, upper);
+    loaded_area_bounds(player_position, wd->n, lower, upper);
     for (int k = 0; k < 3; ++k) {
         inv_rd[k] = 1.0f / rd[k];                 /* :27 */
         s01[k]    = rd[k] > 0.0f ? 1 : 0;         /* :29 */
@@ -295,6 +301,91 @@ int orc_trace(const orc_world *wd, const float m[16], uint32_t w, uint32_t h, ui
         if (i + 1 < nthreads) pthread_create(&th[i], NULL, trace_rows, &jobs[i]);
     }
     trace_rows(&jobs[nthreads - 1]);
+    for (int i = 0; i + 1 < nthreads; ++i) pthread_join(th[i], NULL);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* secondary rays (extension, no reference counterpart)                */
+/* ------------------------------------------------------------------ */
+
+static inline uint32_t pcg_hash(uint32_t v)
+{
+    uint32_t state = v * 747796405u + 2891336453u;
+    uint32_t word  = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+
+void orc_secondary_dir(uint32_t pixel_index, uint32_t index, int32_t face, float rd[3])
+{
+    if (index == 0) { /* light direction */
+        const float lx = 0.4f, ly = 0.8f, lz = 0.45f;
+        const float len = sqrtf((lx * lx + ly * ly) + lz * lz);
+        rd[0] = lx / len; rd[1] = ly / len; rd[2] = lz / len;
+        return;
+    }
+    uint32_t hsh = pcg_hash(0x5EEDu ^ pixel_index);
+    for (uint32_t j = 1; j < index; ++j) { hsh = pcg_hash(hsh); hsh = pcg_hash(hsh); }
+    const uint32_t h1 = hsh, h2 = pcg_hash(hsh);
+    const float u1 = (float)(h1 >> 8) * 0x1.0p-24f, u2 = (float)(h2 >> 8) * 0x1.0p-24f;
+    const float r = sqrtf(u1), phi = 6.2831855f * u2;
+    const float tx = r * orc_sin(phi + 1.5707964f); /* cos */
+    const float ty = r * orc_sin(phi);
+    const float tz = sqrtf(1.0f - u1);
+    const int   k = face >> 1;
+    const float sgn = (face & 1) ? 1.0f : -1.0f;   /* faces 1,3,5 have the + normal */
+    /* normal axis k gets +-tz, the two other axes (in cyclic order) get tx, ty */
+    rd[k] = sgn * tz; rd[(k + 1) % 3] = tx; rd[(k + 2) % 3] = ty;
+}
+
+typedef struct sec_job {
+    const orc_world *wd; const float *m; uint32_t w, h, y0, y1; uint8_t *shadow, *ao; uint32_t *steps;
+    int tid, nthreads;
+} sec_job;
+
+static void *secondary_rows(void *arg)
+{
+    sec_job *j = (sec_job *)arg;
+    for (uint32_t row = j->y0 + (uint32_t)j->tid; row < j->y1; row += (uint32_t)j->nthreads) {
+        for (uint32_t col = 0; col < j->w; ++col) {
+            const size_t i = (size_t)(row - j->y0) * j->w + col;
+            float ro[3], rd[3];
+            orc_ray pr;
+            orc_raygen(j->m, j->w, j->h, col, j->h - row, ro, rd);
+            orc_trace_ray(j->wd, ro, rd, &pr);
+            uint32_t sh = 0, ao = 0, st = 0;
+            if (pr.hit) {
+                float so[3];
+                for (int k = 0; k < 3; ++k) so[k] = pr.hit_point[k] + pr.normal[k] * 1e-3f;
+                for (uint32_t s = 0; s < 5; ++s) {
+                    float sd[3];
+                    orc_ray sr;
+                    orc_secondary_dir(row * j->w + col, s, pr.face, sd);
+                    orc_trace_ray_from(j->wd, ro, so, sd, &sr);
+                    st += sr.steps;
+                    if (sr.hit) { if (s == 0) sh = 1; else ao++; }
+                }
+            }
+            if (j->shadow) j->shadow[i] = (uint8_t)sh;
+            if (j->ao) j->ao[i] = (uint8_t)ao;
+            if (j->steps) j->steps[i] = st;
+        }
+    }
+    return NULL;
+}
+
+int orc_trace_secondary(const orc_world *wd, const float m[16], uint32_t w, uint32_t h, uint32_t y0, uint32_t y1,
+                        uint8_t *shadow, uint8_t *ao, uint32_t *sec_steps, int nthreads)
+{
+    if (!wd || !wd->block || w == 0 || h == 0 || y0 > y1 || y1 > h) return -1;
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 256) nthreads = 256;
+    pthread_t th[256]; sec_job jobs[256];
+    for (int i = 0; i < nthreads; ++i) {
+        jobs[i] = (sec_job){wd, m, w, h, y0, y1, shadow, ao, sec_steps, i, nthreads};
+        if (i + 1 < nthreads) pthread_create(&th[i], NULL, secondary_rows, &jobs[i]);
+    }
+    secondary_rows(&jobs[nthreads - 1]);
     for (int i = 0; i + 1 < nthreads; ++i) pthread_join(th[i], NULL);
     return 0;
 }

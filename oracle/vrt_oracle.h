@@ -74,10 +74,27 @@ void  orc_raygen(const float cam_col_major[16], uint32_t w, uint32_t h,
                  uint32_t gid_x, uint32_t gid_y, float ro[3], float rd[3]);
 /* raytrace.glsl:26-77 */
 void  orc_trace_ray(const orc_world *wd, const float ro[3], const float rd[3], orc_ray *out);
+/* the same traversal for a ray that does not start at the camera: the loaded area
+ * (raytrace.glsl:19-24) is still the one around `player_position` */
+void  orc_trace_ray_from(const orc_world *wd, const float player_position[3], const float ro[3],
+                         const float rd[3], orc_ray *out);
 /* render.comp:6-14 for every pixel of rows [y0,y1) */
 int   orc_trace(const orc_world *wd, const float cam_col_major[16],
                 uint32_t w, uint32_t h, uint32_t y0, uint32_t y1,
                 const orc_outputs *out, int nthreads);
+/* Secondary rays per primary hit -- NO reference counterpart (the shader casts primary rays
+ * only); defined here so that an incoherent-ray workload has an exact CPU statement.
+ * For every pixel of rows [y0,y1) whose primary ray hits: one shadow ray towards the light
+ * normalize(0.4, 0.8, 0.45) and four ambient-occlusion rays, cosine distributed about the face
+ * normal from the hash chain pcg(0x5EED ^ (row*w + col)); origin = hit_point + normal*1e-3;
+ * all traced by the same traversal in the camera's loaded area.
+ * shadow: 1 if the shadow ray hits, else 0; ao: number of AO rays that hit (0..4);
+ * sec_steps: sum of the loop iterations of the five rays.  All 0 for primary misses. */
+int   orc_trace_secondary(const orc_world *wd, const float cam_col_major[16], uint32_t w, uint32_t h,
+                          uint32_t y0, uint32_t y1, uint8_t *shadow, uint8_t *ao, uint32_t *sec_steps,
+                          int nthreads);
+/* direction of secondary ray `index` (0 shadow, 1..4 AO) of pixel `pixel_index` on `face` */
+void  orc_secondary_dir(uint32_t pixel_index, uint32_t index, int32_t face, float rd[3]);
 /* canonical sine used by the shading term (raytrace.glsl:130) */
 float orc_sin(float x);
 /* noise.glsl:7-74 */

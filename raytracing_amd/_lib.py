@@ -39,6 +39,11 @@ class VrtOutputs(C.Structure):
                 ("rgba", C.c_void_p)]
 
 
+class VrtSecondaryOutputs(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("memory", C.c_uint32), ("shadow", C.c_void_p), ("ao", C.c_void_p),
+                ("sec_steps", C.c_void_p)]
+
+
 # every symbol include/vrt.h declares: name -> (restype, argtypes)
 _F = C.POINTER(C.c_float)
 _CTX = C.c_void_p
@@ -50,6 +55,8 @@ SYMBOLS = {
     "vrt_generate_window": (C.c_int, [_CTX, C.POINTER(C.c_int32)]),
     "vrt_reset_distance_field": (C.c_int, [_CTX]),
     "vrt_trace": (C.c_int, [_CTX, _F, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(VrtOutputs)]),
+    "vrt_trace_secondary": (C.c_int, [_CTX, _F, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                      C.POINTER(VrtSecondaryOutputs)]),
     "vrt_trace_strips": (C.c_int, [_CTX, _F, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                    C.POINTER(VrtOutputs)]),
     "vrt_strip_rows": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),

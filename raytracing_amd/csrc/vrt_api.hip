@@ -122,11 +122,11 @@ int window_offcy(const vrt_ctx *c, float y)
 
 struct Plane { size_t off, bytes; void *host; };
 
-int do_trace(vrt_ctx *c, const float *cam, uint32_t w, uint32_t h, const vrt::RowMap &rows, const vrt_outputs *out)
+// argument checks, kernel choice and the parameter block shared by every trace entry point
+int prepare_trace(vrt_ctx *c, const float *cam, uint32_t w, uint32_t h, const vrt::RowMap &rows, bool need_skip,
+                  vrt::TraceParams &p, bool &use_skip)
 {
-    if (!c || !cam || !out) return fail(VRT_E_INVALID_ARG, "null argument");
-    if (out->struct_size != sizeof(vrt_outputs)) return fail(VRT_E_INVALID_ARG, "vrt_outputs.struct_size mismatch");
-    if (out->memory != VRT_MEM_HOST && out->memory != VRT_MEM_DEVICE) return fail(VRT_E_INVALID_ARG, "bad outputs.memory");
+    if (!c || !cam) return fail(VRT_E_INVALID_ARG, "null argument");
     if (w == 0 || h == 0 || w > 16384 || h > 16384) return fail(VRT_E_INVALID_ARG, "frame size out of range");
     for (int i = 0; i < 16; ++i)
         if (!std::isfinite(cam[i])) return fail(VRT_E_INVALID_ARG, "camera transform is not finite");
@@ -135,7 +135,6 @@ int do_trace(vrt_ctx *c, const float *cam, uint32_t w, uint32_t h, const vrt::Ro
     if (!c->have_world) return fail(VRT_E_NO_WORLD, "no world uploaded or generated");
     HIP_TRY(hipSetDevice(c->device));
 
-    bool use_skip;
     switch (c->trace_mode) {
         case VRT_TRACE_LITERAL: use_skip = false; break;
         case VRT_TRACE_SKIP:
@@ -144,12 +143,15 @@ int do_trace(vrt_ctx *c, const float *cam, uint32_t w, uint32_t h, const vrt::Ro
             break;
         default: use_skip = !c->dist_nonzero; break;
     }
+    if (need_skip) {
+        if (c->dist_nonzero) return fail(VRT_E_UNSUPPORTED, "secondary rays need an all-zero distance image");
+        use_skip = true;
+    }
     if (use_skip) {
         int rc = ensure_skip_structure(c, window_offcy(c, cam[13]));
         if (rc != VRT_OK) return rc;
     }
 
-    vrt::TraceParams p;
     std::memset(&p, 0, sizeof p);
     std::memcpy(p.m, cam, sizeof p.m);
     p.w = w; p.h = h; p.rows = rows;
@@ -157,10 +159,31 @@ int do_trace(vrt_ctx *c, const float *cam, uint32_t w, uint32_t h, const vrt::Ro
     p.n_pow2_mask = (c->n & (c->n - 1)) == 0 ? (int)c->n - 1 : -1;
     p.max_steps = c->max_steps;
     { const char *v = std::getenv("VRT_SKIP_VARIANT"); p.variant = v ? (uint32_t)std::atoi(v) : 0u; }  // A/B only
-    { const char *v = std::getenv("VRT_DEBUG_ITERS"); p.debug_iters = v ? (uint32_t)std::atoi(v) : 0u; }  // diagnostic only
+    { const char *v = std::getenv("VRT_DEBUG_ITERS"); p.debug_iters = v ? (uint32_t)std::atoi(v) : 0u; }
     p.block = c->d_block;
     p.dist = c->dist_nonzero ? c->d_dist : nullptr;
     p.cells = c->d_cells; p.nc = (int)c->n / 4;
+    return VRT_OK;
+}
+
+int ensure_stage(vrt_ctx *c, size_t total)
+{
+    if (total > c->stage_bytes) {
+        if (c->d_stage) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_stage)); c->d_stage = nullptr; c->stage_bytes = 0; }
+        HIP_TRY(hipMalloc(&c->d_stage, total));
+        c->stage_bytes = total;
+    }
+    return VRT_OK;
+}
+
+int do_trace(vrt_ctx *c, const float *cam, uint32_t w, uint32_t h, const vrt::RowMap &rows, const vrt_outputs *out)
+{
+    if (!c || !cam || !out) return fail(VRT_E_INVALID_ARG, "null argument");
+    if (out->struct_size != sizeof(vrt_outputs)) return fail(VRT_E_INVALID_ARG, "vrt_outputs.struct_size mismatch");
+    if (out->memory != VRT_MEM_HOST && out->memory != VRT_MEM_DEVICE) return fail(VRT_E_INVALID_ARG, "bad outputs.memory");
+    vrt::TraceParams p;
+    bool use_skip = false;
+    { int rc = prepare_trace(c, cam, w, h, rows, false, p, use_skip); if (rc != VRT_OK) return rc; }
 
     const size_t px = (size_t)rows.rows * w;
     Plane planes[7] = {{0, out->bgra8 ? px * 4 : 0, out->bgra8},       {0, out->voxel ? px * 12 : 0, out->voxel},
@@ -173,11 +196,7 @@ int do_trace(vrt_ctx *c, const float *cam, uint32_t w, uint32_t h, const vrt::Ro
     } else {
         size_t total = 0;
         for (int i = 0; i < 7; ++i) { planes[i].off = total; total += (planes[i].bytes + 255) & ~(size_t)255; }
-        if (total > c->stage_bytes) {
-            if (c->d_stage) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_stage)); c->d_stage = nullptr; c->stage_bytes = 0; }
-            HIP_TRY(hipMalloc(&c->d_stage, total));
-            c->stage_bytes = total;
-        }
+        { int rc = ensure_stage(c, total); if (rc != VRT_OK) return rc; }
         for (int i = 0; i < 7; ++i) dev[i] = planes[i].bytes ? (char *)c->d_stage + planes[i].off : nullptr;
     }
     p.bgra8 = (uint8_t *)dev[0]; p.voxel = (int32_t *)dev[1]; p.face = (int32_t *)dev[2]; p.steps = (uint32_t *)dev[3];
@@ -335,6 +354,44 @@ int vrt_trace(vrt_ctx *c, const float cam[16], uint32_t w, uint32_t h, uint32_t 
     if (y0 > y1 || y1 > h) return fail(VRT_E_INVALID_ARG, "row band [%u,%u) outside the frame", y0, y1);
     vrt::RowMap rows{y0, y1 - y0, 0, 0, 1};
     return do_trace(c, cam, w, h, rows, out);
+}
+
+int vrt_trace_secondary(vrt_ctx *c, const float cam[16], uint32_t w, uint32_t h, uint32_t y0, uint32_t y1,
+                        const vrt_secondary_outputs *out)
+{
+    if (!c || !cam || !out) return fail(VRT_E_INVALID_ARG, "null argument");
+    if (out->struct_size != sizeof(vrt_secondary_outputs)) return fail(VRT_E_INVALID_ARG, "vrt_secondary_outputs.struct_size mismatch");
+    if (out->memory != VRT_MEM_HOST && out->memory != VRT_MEM_DEVICE) return fail(VRT_E_INVALID_ARG, "bad outputs.memory");
+    if (y0 > y1 || y1 > h) return fail(VRT_E_INVALID_ARG, "row band [%u,%u) outside the frame", y0, y1);
+    vrt::RowMap rows{y0, y1 - y0, 0, 0, 1};
+    vrt::TraceParams p;
+    bool use_skip = false;
+    { int rc = prepare_trace(c, cam, w, h, rows, true, p, use_skip); if (rc != VRT_OK) return rc; }
+    const size_t px = (size_t)rows.rows * w;
+    Plane planes[3] = {{0, out->shadow ? px : 0, out->shadow}, {0, out->ao ? px : 0, out->ao},
+                       {0, out->sec_steps ? px * 4 : 0, out->sec_steps}};
+    void *dev[3];
+    if (out->memory == VRT_MEM_DEVICE) {
+        for (int i = 0; i < 3; ++i) dev[i] = planes[i].host;
+    } else {
+        size_t total = 0;
+        for (int i = 0; i < 3; ++i) { planes[i].off = total; total += (planes[i].bytes + 255) & ~(size_t)255; }
+        { int rc = ensure_stage(c, total); if (rc != VRT_OK) return rc; }
+        for (int i = 0; i < 3; ++i) dev[i] = planes[i].bytes ? (char *)c->d_stage + planes[i].off : nullptr;
+    }
+    if (c->ev_pending == kEventRing) { int rc = drain_events(c); if (rc != VRT_OK) return rc; }
+    const int e = c->ev_pending;
+    HIP_TRY(hipEventRecord(c->ev0[e], c->stream));
+    HIP_TRY(vrt::launch_trace_secondary(p, c->voxel_bytes, (uint8_t *)dev[0], (uint8_t *)dev[1], (uint32_t *)dev[2], c->stream));
+    c->last_kernel = "secondary";
+    HIP_TRY(hipEventRecord(c->ev1[e], c->stream));
+    c->ev_pending = e + 1;
+    if (out->memory == VRT_MEM_HOST) {
+        for (int i = 0; i < 3; ++i)
+            if (planes[i].bytes) HIP_TRY(hipMemcpyAsync(planes[i].host, dev[i], planes[i].bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return VRT_OK;
 }
 
 uint32_t vrt_strip_rows(uint32_t h, uint32_t strip_h, uint32_t part, uint32_t parts)

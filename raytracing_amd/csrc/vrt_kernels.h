@@ -54,6 +54,8 @@ struct TraceParams {
 // traversal kernels
 hipError_t launch_trace_literal(const TraceParams &p, int voxel_bytes, hipStream_t s);
 hipError_t launch_trace_skip(const TraceParams &p, int voxel_bytes, hipStream_t s);
+hipError_t launch_trace_secondary(const TraceParams &p, int voxel_bytes, uint8_t *shadow, uint8_t *ao,
+                                  uint32_t *sec_steps, hipStream_t s);
 
 // world kernels
 hipError_t launch_terrain(void *block, int voxel_bytes, int n, int x0, int y0, int z0,

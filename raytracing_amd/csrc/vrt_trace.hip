@@ -391,6 +391,78 @@ __global__ __launch_bounds__(256) void k_trace_skip(const TraceParams P)
     finish_pixel(P, gx, gy, (size_t)q * P.w + col, H);
 }
 
+// ---------------------------------------------------------------------------
+// secondary rays per primary hit (no reference counterpart: the shader casts primary rays
+// only).  One shadow ray towards normalize(0.4, 0.8, 0.45) and four cosine-distributed
+// ambient-occlusion rays about the face normal, from the hash chain pcg(0x5EED ^ pixel);
+// origin = hit_point + normal*1e-3; same traversal, same loaded area as the camera.
+// ---------------------------------------------------------------------------
+VRT_DEV unsigned pcg_hash(unsigned v)
+{
+    const unsigned state = v * 747796405u + 2891336453u;
+    const unsigned word  = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+
+VRT_DEV void secondary_dir(unsigned pixel_index, unsigned index, int face, float &dx, float &dy, float &dz)
+{
+    if (index == 0) {
+        const float lx = 0.4f, ly = 0.8f, lz = 0.45f;
+        const float len = sqrtf((lx * lx + ly * ly) + lz * lz);
+        dx = lx / len; dy = ly / len; dz = lz / len;
+        return;
+    }
+    unsigned hsh = pcg_hash(0x5EEDu ^ pixel_index);
+    for (unsigned j = 1; j < index; ++j) { hsh = pcg_hash(hsh); hsh = pcg_hash(hsh); }
+    const unsigned h1 = hsh, h2 = pcg_hash(hsh);
+    const float u1 = (float)(h1 >> 8) * 0x1.0p-24f, u2 = (float)(h2 >> 8) * 0x1.0p-24f;
+    const float r = sqrtf(u1), phi = 6.2831855f * u2;
+    const float tx = r * canon_sin(phi + 1.5707964f);
+    const float ty = r * canon_sin(phi);
+    const float tz = sqrtf(1.0f - u1);
+    const int   k = face >> 1;
+    const float nz = (face & 1) ? tz : -tz;
+    // normal axis k gets +-tz, the two other axes (in cyclic order) get tx, ty
+    dx = k == 0 ? nz : (k == 2 ? tx : ty);
+    dy = k == 1 ? nz : (k == 0 ? tx : ty);
+    dz = k == 2 ? nz : (k == 1 ? tx : ty);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_trace_secondary(const TraceParams P, uint8_t *shadow, uint8_t *ao, uint32_t *sec_steps)
+{
+    unsigned col, q, row;
+    if (!pixel_of_thread(P, col, q, row)) return;
+    const unsigned gx = col, gy = P.h - row;
+    float rdx, rdy, rdz;
+    raygen(P, gx, gy, rdx, rdy, rdz);
+    const float rox = P.m[12], roy = P.m[13], roz = P.m[14];
+    int lox, loy, loz, upx, upy, upz;
+    loaded_area(P, rox, lox, upx); loaded_area(P, roy, loy, upy); loaded_area(P, roz, loz, upz);
+    RayHit H;
+    traverse_skip<T>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
+    unsigned sh = 0, occ = 0, st = 0;
+    if (H.hit) {
+        const float nk = (float)(-H.sk);
+        const float sox = H.hx + (H.k == 0 ? nk : 0.0f) * 1e-3f;
+        const float soy = H.hy + (H.k == 1 ? nk : 0.0f) * 1e-3f;
+        const float soz = H.hz + (H.k == 2 ? nk : 0.0f) * 1e-3f;
+        const int face = 2 * H.k + (H.sk < 0 ? 1 : 0);
+        for (unsigned s = 0; s < 5; ++s) {
+            float sdx, sdy, sdz;
+            secondary_dir(row * P.w + col, s, face, sdx, sdy, sdz);
+            RayHit S;
+            traverse_skip<T>(P, sox, soy, soz, sdx, sdy, sdz, lox, loy, loz, upx, upy, upz, S);
+            st += S.steps;
+            if (S.hit) { if (s == 0) sh = 1; else ++occ; }
+        }
+    }
+    const size_t i = (size_t)q * P.w + col;
+    if (shadow) shadow[i] = (uint8_t)sh;
+    if (ao) ao[i] = (uint8_t)occ;
+    if (sec_steps) sec_steps[i] = st;
+}
+
 static dim3 trace_grid(const TraceParams &p) { return dim3((p.w + 15) / 16, (p.rows.rows + 15) / 16, 1); }
 
 hipError_t launch_trace_literal(const TraceParams &p, int voxel_bytes, hipStream_t s)
@@ -404,6 +476,16 @@ hipError_t launch_trace_literal(const TraceParams &p, int voxel_bytes, hipStream
     } else {
         k_trace_literal<uint16_t, false><<<grid, block, 0, s>>>(p);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_trace_secondary(const TraceParams &p, int voxel_bytes, uint8_t *shadow, uint8_t *ao,
+                                  uint32_t *sec_steps, hipStream_t s)
+{
+    if (p.rows.rows == 0 || p.w == 0) return hipSuccess;
+    const dim3 grid = trace_grid(p), block(256);
+    if (voxel_bytes == 1) k_trace_secondary<uint8_t><<<grid, block, 0, s>>>(p, shadow, ao, sec_steps);
+    else k_trace_secondary<uint16_t><<<grid, block, 0, s>>>(p, shadow, ao, sec_steps);
     return hipGetLastError();
 }
 

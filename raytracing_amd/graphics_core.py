@@ -142,6 +142,24 @@ class GraphicsCore:
         L.check(L.lib().vrt_trace(self._ctx, camp, w, h, y0, y1, C.byref(o)))
         return res
 
+    def trace_secondary(self, cam, w, h, y0=0, y1=None):
+        """Shadow + 4 ambient-occlusion rays per primary hit (an extension without a reference
+        counterpart); returns host planes shadow (u8), ao (u8), sec_steps (u32)."""
+        y1 = h if y1 is None else y1
+        rows = max(0, y1 - y0)
+        cam, camp = self._cam(cam)
+        res = {"shadow": np.empty((rows, w), np.uint8), "ao": np.empty((rows, w), np.uint8),
+               "sec_steps": np.empty((rows, w), np.uint32)}
+        o = L.VrtSecondaryOutputs(C.sizeof(L.VrtSecondaryOutputs), L.MEM_HOST, res["shadow"].ctypes.data,
+                                  res["ao"].ctypes.data, res["sec_steps"].ctypes.data)
+        L.check(L.lib().vrt_trace_secondary(self._ctx, camp, w, h, y0, y1, C.byref(o)))
+        return res
+
+    def trace_secondary_device(self, cam, w, h, y0, y1, shadow=None, ao=None, sec_steps=None):
+        cam, camp = self._cam(cam)
+        o = L.VrtSecondaryOutputs(C.sizeof(L.VrtSecondaryOutputs), L.MEM_DEVICE, shadow, ao, sec_steps)
+        L.check(L.lib().vrt_trace_secondary(self._ctx, camp, w, h, y0, y1, C.byref(o)))
+
     def trace_strips(self, cam, w, h, strip_h, part, parts, outputs=("bgra8",)):
         rows = L.lib().vrt_strip_rows(h, strip_h, part, parts)
         cam, camp = self._cam(cam)

@@ -51,6 +51,13 @@ def lib():
         L.orc_trace.argtypes = [C.POINTER(OrcWorld), F3, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                 C.POINTER(OrcOutputs), C.c_int]
         L.orc_trace.restype = C.c_int
+        L.orc_trace_secondary.argtypes = [C.POINTER(OrcWorld), F3, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_trace_secondary.restype = C.c_int
+        L.orc_secondary_dir.argtypes = [C.c_uint32, C.c_uint32, C.c_int32, F3]
+        L.orc_secondary_dir.restype = None
+        L.orc_trace_ray_from.argtypes = [C.POINTER(OrcWorld), F3, F3, F3, C.POINTER(OrcRay)]
+        L.orc_trace_ray_from.restype = None
         L.orc_sin.argtypes = [C.c_float]
         L.orc_sin.restype = C.c_float
         L.orc_snoise.argtypes = [C.c_float] * 3
@@ -130,6 +137,25 @@ def trace(world, cam, w, h, y0=0, y1=None, nthreads=None, want=("bgra8", "voxel"
     if rc != 0:
         raise ValueError("orc_trace rejected its arguments")
     return out
+
+
+def trace_secondary(world, cam, w, h, y0=0, y1=None, nthreads=None):
+    y1 = h if y1 is None else y1
+    rows = y1 - y0
+    cam = np.ascontiguousarray(cam, dtype=np.float32).reshape(16)
+    out = {"shadow": np.zeros((rows, w), np.uint8), "ao": np.zeros((rows, w), np.uint8),
+           "sec_steps": np.zeros((rows, w), np.uint32)}
+    rc = lib().orc_trace_secondary(world.c(), _fp(cam), w, h, y0, y1, out["shadow"].ctypes.data,
+                                   out["ao"].ctypes.data, out["sec_steps"].ctypes.data, nthreads or host_threads())
+    if rc != 0:
+        raise ValueError("orc_trace_secondary rejected its arguments")
+    return out
+
+
+def secondary_dir(pixel_index, index, face):
+    rd = np.zeros(3, np.float32)
+    lib().orc_secondary_dir(pixel_index, index, face, _fp(rd))
+    return rd
 
 
 def sin(x):

@@ -1,0 +1,295 @@
+// graphics_core.hpp -- C++ host-side mirror of the reference's interface for the trace path,
+// on top of the C ABI (vrt.h).  Header only; needs nothing but the standard library.
+//
+// The reference is a Rust crate and no Rust toolchain exists where this was built, so the
+// host side is written in C++ with the reference's names, argument meaning and error
+// behaviour, for callers that drive the path the way src/main.rs and src/game_logic do:
+//
+//   GraphicsCore   src/graphics/mod.rs:134-148,150-183,245-291,292-428,430-475,531-634
+//   PushConstants  src/graphics/push_constants.rs:4-9
+//   GraphicsSettings src/graphics/graphics_settings.rs:1-17
+//   Player         src/game_logic/player/mod.rs:5-64
+//   KeyStates      src/game_logic/key_states.rs:4-35
+//   GameState      src/game_logic/game_state.rs:10-89
+//
+// What is NOT mirrored: window, swapchain, event loop and input devices (presentation, not
+// part of this path).  `GraphicsCore::run` therefore takes a frame count and an optional
+// per-frame input callback instead of never returning, and `redraw` leaves the
+// B8G8R8A8 frame in host memory (`frame()`) instead of presenting it.  Errors are C++
+// exceptions where the reference panics (`unwrap`).
+#pragma once
+
+#include "vrt.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <functional>
+#include <set>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace tube {  // the reference crate's name (Cargo.toml:2)
+
+struct Vector3f { float x = 0, y = 0, z = 0; };
+struct Vector3i {
+    int32_t x = 0, y = 0, z = 0;
+    int32_t amax() const { return std::max(std::abs(x), std::max(std::abs(y), std::abs(z))); }
+};
+inline Vector3i operator+(Vector3i a, Vector3i b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline Vector3i operator-(Vector3i a, Vector3i b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+
+// nalgebra Matrix4<f32>: column major, m[4*col + row] (= GLSL mat4).
+struct Matrix4 {
+    float m[16];
+    static Matrix4 identity()
+    {
+        Matrix4 r{};
+        for (int i = 0; i < 16; ++i) r.m[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+        return r;
+    }
+    float &at(int row, int col) { return m[4 * col + row]; }
+    float at(int row, int col) const { return m[4 * col + row]; }
+    // Matrix4::from_scaled_axis: rotation by |v| about v/|v| (Rodrigues), identity for v = 0
+    static Matrix4 from_scaled_axis(Vector3f v)
+    {
+        Matrix4 r = identity();
+        const float angle = std::sqrt(v.x * v.x + v.y * v.y + v.z * v.z);
+        if (angle == 0.0f) return r;
+        const float ux = v.x / angle, uy = v.y / angle, uz = v.z / angle;
+        const float s = std::sin(angle), c = std::cos(angle), omc = 1.0f - c;
+        r.at(0, 0) = ux * ux + (1.0f - ux * ux) * c; r.at(0, 1) = ux * uy * omc - uz * s; r.at(0, 2) = ux * uz * omc + uy * s;
+        r.at(1, 0) = ux * uy * omc + uz * s; r.at(1, 1) = uy * uy + (1.0f - uy * uy) * c; r.at(1, 2) = uy * uz * omc - ux * s;
+        r.at(2, 0) = ux * uz * omc - uy * s; r.at(2, 1) = uy * uz * omc + ux * s; r.at(2, 2) = uz * uz + (1.0f - uz * uz) * c;
+        return r;
+    }
+};
+inline Matrix4 operator*(const Matrix4 &a, const Matrix4 &b)
+{
+    Matrix4 r{};
+    for (int col = 0; col < 4; ++col)
+        for (int row = 0; row < 4; ++row) {
+            float acc = 0.0f;
+            for (int k = 0; k < 4; ++k) acc += a.at(row, k) * b.at(k, col);
+            r.at(row, col) = acc;
+        }
+    return r;
+}
+
+// #[repr(C)] struct PushConstants { transform: Matrix4<f32>, image_index: u32 }  (68 bytes)
+struct PushConstants {
+    Matrix4  transform;
+    uint32_t image_index;
+};
+static_assert(sizeof(PushConstants) == 68, "PushConstants must match the shader's push-constant block");
+
+struct GraphicsSettings {  // graphics_settings.rs:9-16
+    uint8_t render_distance = 1;
+    double  fov = 90.0;  // never read by the reference either
+    float   mouse_sensitivity[2] = {0.002f, 0.002f};
+};
+
+enum class VirtualKeyCode { W, A, S, D, Space, LShift, T, R, Escape };
+
+struct KeyStates {  // key_states.rs:4-35
+    std::set<VirtualKeyCode> currently_pressed, new_pressed;
+    void update(VirtualKeyCode key, bool pressed)
+    {
+        if (pressed) { if (currently_pressed.insert(key).second) new_pressed.insert(key); }
+        else currently_pressed.erase(key);
+    }
+    void reset() { new_pressed.clear(); }
+};
+
+class GameState;
+
+// Stands in for `Option<Box<dyn GpuFuture>>` (src/graphics/mod.rs:140): game_state.rs:77 calls
+// previous_frame_end.take().unwrap().then_signal_fence_and_flush().unwrap().wait(None).unwrap().
+struct FrameToken {
+    vrt_ctx *ctx = nullptr;
+    FrameToken then_signal_fence_and_flush() const { return *this; }
+    void wait() const
+    {
+        if (vrt_sync(ctx) != VRT_OK) throw std::runtime_error(vrt_last_error());
+    }
+};
+
+class GraphicsCore {
+public:
+    static constexpr uint32_t CHUNK_SIZE = 32;                                   // mod.rs:147
+    static constexpr uint32_t CHUNK_SIZE_3 = CHUNK_SIZE * CHUNK_SIZE * CHUNK_SIZE; // mod.rs:148
+
+    // ≙ GraphicsCore::new (mod.rs:292-425) without the window: `width` x `height` is the size the
+    // window's inner_size() would report; the world images have extent 32*(2*render_distance+3).
+    explicit GraphicsCore(uint32_t width = 640, uint32_t height = 480, int device = 0,
+                          GraphicsSettings settings = GraphicsSettings())
+        : settings_(settings), width_(width), height_(height)
+    {
+        vrt_config cfg{};
+        cfg.struct_size  = sizeof cfg;
+        cfg.device       = device;
+        cfg.grid_n       = CHUNK_SIZE * (2u * settings.render_distance + 3u);  // mod.rs:359
+        cfg.voxel_format = VRT_VOXEL_REF_U16U16;
+        cfg.max_steps    = 0;
+        cfg.trace_mode   = VRT_TRACE_AUTO;
+        check(vrt_create(&cfg, &ctx_));
+        previous_frame_end = FrameToken{ctx_};
+        frame_.resize((size_t)width_ * height_ * 4);
+    }
+    ~GraphicsCore() { vrt_destroy(ctx_); }
+    GraphicsCore(const GraphicsCore &) = delete;
+    GraphicsCore &operator=(const GraphicsCore &) = delete;
+
+    GraphicsSettings get_settings() const { return settings_; }  // mod.rs:426-428
+
+    // mod.rs:245-291
+    void upload_chunk_gpu(Vector3i chunk_pos, GameState &) { check(vrt_generate_chunk(ctx_, chunk_pos.x, chunk_pos.y, chunk_pos.z)); }
+    // mod.rs:150-183
+    void reset_distance_field() { check(vrt_reset_distance_field(ctx_)); }
+
+    // mod.rs:531-634: returns true when the frame was skipped (zero-sized window)
+    bool redraw(const PushConstants &push_constants)
+    {
+        if (width_ == 0 || height_ == 0) return true;  // mod.rs:534-536
+        vrt_outputs out{};
+        out.struct_size = sizeof out;
+        out.memory      = VRT_MEM_HOST;
+        out.bgra8       = frame_.data();
+        check(vrt_trace(ctx_, push_constants.transform.m, width_, height_, 0, height_, &out));
+        return false;
+    }
+
+    // mod.rs:430-475 without the OS event loop: `frames` redraws; `input` is called before each
+    // frame in place of the window/device events the reference feeds into game_state.
+    void run(GameState &game_state, const std::function<PushConstants(GraphicsCore &, GameState &)> &game_update,
+             uint32_t frames, const std::function<void(uint32_t, GameState &)> &input = nullptr);
+
+    void resize(uint32_t width, uint32_t height)  // ≙ WindowEvent::Resized -> recreate_swapchain
+    {
+        width_ = width; height_ = height;
+        frame_.assign((size_t)width_ * height_ * 4, 0);
+    }
+    const std::vector<uint8_t> &frame() const { return frame_; }  // B,G,R,A bytes, rows top to bottom
+    uint32_t width() const { return width_; }
+    uint32_t height() const { return height_; }
+    vrt_ctx *context() { return ctx_; }
+
+    FrameToken previous_frame_end;  // pub(crate) in the reference; game_state.rs:77-79 touches it
+
+private:
+    static void check(int rc)
+    {
+        if (rc != VRT_OK) throw std::runtime_error(std::string("vrt: ") + vrt_last_error());
+    }
+    vrt_ctx             *ctx_ = nullptr;
+    GraphicsSettings     settings_;
+    uint32_t             width_, height_;
+    std::vector<uint8_t> frame_;
+};
+
+class Player {  // player/mod.rs:5-64
+public:
+    static constexpr float BASE_SPEED = 0.02f;
+    float look_direction[2] = {0.0f, 0.0f};  // (yaw, pitch)
+
+    static Player spawn() { return Player(); }
+    Matrix4  get_transform() const { return matrix_; }
+    Vector3f get_position() const { return {matrix_.at(0, 3), matrix_.at(1, 3), matrix_.at(2, 3)}; }
+    void     set_position(Vector3f p) { matrix_.at(0, 3) = p.x; matrix_.at(1, 3) = p.y; matrix_.at(2, 3) = p.z; }
+    void apply_rotation()  // :25-30  matrix = T * Rx(pitch) * Ry(yaw)
+    {
+        reset_rotation();
+        const Matrix4 transform = Matrix4::from_scaled_axis({look_direction[1], 0, 0}) * Matrix4::from_scaled_axis({0, look_direction[0], 0});
+        matrix_ = matrix_ * transform;
+    }
+    void update_pos(const std::set<VirtualKeyCode> &keys, float speed_modifier)  // :37-63
+    {
+        const float yaw = look_direction[0];
+        const Vector3f forward{-std::sin(yaw), 0.0f, std::cos(yaw)}, right{std::cos(yaw), 0.0f, std::sin(yaw)}, up{0, 1, 0};
+        Vector3f mov;
+        auto add = [&](Vector3f v, float s) { mov.x += s * v.x; mov.y += s * v.y; mov.z += s * v.z; };
+        if (keys.count(VirtualKeyCode::W)) add(forward, 1);
+        if (keys.count(VirtualKeyCode::A)) add(right, -1);
+        if (keys.count(VirtualKeyCode::S)) add(forward, -1);
+        if (keys.count(VirtualKeyCode::D)) add(right, 1);
+        if (keys.count(VirtualKeyCode::Space)) add(up, 1);
+        if (keys.count(VirtualKeyCode::LShift)) add(up, -1);
+        const float cap = BASE_SPEED * speed_modifier;
+        const float norm = std::sqrt(mov.x * mov.x + mov.y * mov.y + mov.z * mov.z);
+        if (norm > cap) { const float s = cap / norm; mov.x *= s; mov.y *= s; mov.z *= s; }  // cap_magnitude
+        matrix_.at(0, 3) += mov.x; matrix_.at(1, 3) += mov.y; matrix_.at(2, 3) += mov.z;      // append_translation_mut
+    }
+
+private:
+    void reset_rotation()  // :32-36
+    {
+        const Vector3f t = get_position();
+        matrix_ = Matrix4::identity();
+        set_position(t);
+    }
+    Matrix4 matrix_ = Matrix4::identity();
+};
+
+class GameState {  // game_state.rs:10-89
+public:
+    Player    player = Player::spawn();
+    KeyStates key_states;
+    float     speed_modifier = 1.0f;
+
+    explicit GameState(GraphicsCore &render_core) { upload_chunks_around_player(render_core, nullptr); }  // :27-39
+
+    Vector3i current_player_chunk() const  // :20-22
+    {
+        const Vector3f p = player.get_position();
+        const float cs = (float)GraphicsCore::CHUNK_SIZE;
+        return {(int32_t)std::floor(p.x / cs), (int32_t)std::floor(p.y / cs), (int32_t)std::floor(p.z / cs)};
+    }
+    void player_look_dir(double dx, double dy, const float sens[2])  // :23-26
+    {
+        player.look_direction[0] = player.look_direction[0] - (float)dx * sens[0];
+        player.look_direction[1] = std::min(1.7f, std::max(-1.7f, player.look_direction[1] - (float)dy * sens[1]));
+    }
+    void update_player(float speed, GraphicsCore &render_core)  // :41-48
+    {
+        const Vector3i old_chunk = current_player_chunk();
+        player.apply_rotation();
+        player.update_pos(key_states.currently_pressed, speed);
+        upload_chunks_around_player(render_core, &old_chunk);
+    }
+    // :50-83; returns the number of chunks regenerated
+    int upload_chunks_around_player(GraphicsCore &core, const Vector3i *old_chunk)
+    {
+        const Vector3i new_chunk = current_player_chunk();
+        if (old_chunk && (new_chunk - *old_chunk).amax() == 0) return 0;
+        const int gen_dist = (int)core.get_settings().render_distance + 1;
+        int count = 0;
+        for (int x = -gen_dist; x <= gen_dist; ++x)
+            for (int y = -gen_dist; y <= gen_dist; ++y)
+                for (int z = -gen_dist; z <= gen_dist; ++z) {
+                    const Vector3i chunk_position = new_chunk + Vector3i{x, y, z};
+                    if (old_chunk && (chunk_position - *old_chunk).amax() <= gen_dist) continue;
+                    core.upload_chunk_gpu(chunk_position, *this);
+                    ++count;
+                }
+        core.previous_frame_end.then_signal_fence_and_flush().wait();  // :77
+        core.reset_distance_field();                                    // :82
+        return count;
+    }
+    Matrix4 get_player_transform() const { return player.get_transform(); }  // :86-88
+};
+
+inline void GraphicsCore::run(GameState &game_state,
+                              const std::function<PushConstants(GraphicsCore &, GameState &)> &game_update,
+                              uint32_t frames, const std::function<void(uint32_t, GameState &)> &input)
+{
+    for (uint32_t f = 0; f < frames; ++f) {
+        if (input) input(f, game_state);                 // ≙ keyboard / mouse events (mod.rs:437-454)
+        const PushConstants pc = game_update(*this, game_state);  // ≙ RedrawEventsCleared (mod.rs:467-471)
+        if (redraw(pc)) continue;
+        game_state.key_states.reset();
+    }
+}
+
+}  // namespace tube

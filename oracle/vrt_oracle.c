@@ -15,8 +15,8 @@
  *   - round() = round-half-to-even (rintf);
  *   - normalize(v) = v / sqrt((x*x + y*y) + z*z), one IEEE division per component;
  *   - vector*matrix and dot products sum left to right;
- *   - sin() = orc_sin below (double-precision argument reduction + odd
- *     polynomial, rounded once to float);
+ *   - sin() = orc_sin below (binary32 three-term reduction against pi + odd
+ *     Taylor polynomial through r^11, every operation in the order written);
  *   - UNORM8 store = floor(clamp01(v)*255 + 0.5), NaN -> 0;
  *   - a step cap (max_steps) ends rays the reference would trace forever.
  */
@@ -64,32 +64,26 @@ static inline int argmin3(const float a[3])
     return min_index;
 }
 
-/* Canonical sine.  x is reduced in double against pi split as HI (33 bits, so
- * q*HI is exact for |q| < 2^20) + LO, then an odd Taylor polynomial through
- * r^17 on [-pi/2, pi/2] (truncation error < 5e-14), rounded once to float.
- * Non-finite or |x| >= 2^20 gives NaN. */
+/* Canonical sine, binary32 throughout.  k = rint(x/pi); the reduction x - k*pi uses pi split
+ * into P1 = 3.125 (5 bits: k*P1 is exact for |k| < 2^19, and x - k*P1 is exact), P2 (8 bits)
+ * and P3; then the odd Taylor polynomial through r^11 on [-pi/2, pi/2].  Absolute error
+ * below 3e-7 for |x| < 2^20; non-finite x or |x| >= 2^20 gives NaN. */
 float orc_sin(float x)
 {
-    static const double INV_PI = 0x1.45f306dc9c883p-2;
-    static const double PI_HI  = 0x1.921fb54400000p+1;
-    static const double PI_LO  = 0x1.0b4611a626331p-33;
-    double xd = (double)x;
-    if (!(fabs(xd) < 1048576.0)) return NAN;
-    double q  = rint(xd * INV_PI);
-    double r  = (xd - q * PI_HI) - q * PI_LO;
-    double r2 = r * r;
-    double p  = 0x1.952c77030ad4ap-49;
-    p = p * r2 + -0x1.ae7f3e733b81fp-41;
-    p = p * r2 + 0x1.6124613a86d09p-33;
-    p = p * r2 + -0x1.ae64567f544e4p-26;
-    p = p * r2 + 0x1.71de3a556c734p-19;
-    p = p * r2 + -0x1.a01a01a01a01ap-13;
-    p = p * r2 + 0x1.1111111111111p-7;
-    p = p * r2 + -0x1.5555555555555p-3;
-    double s = r + (r * r2) * p;
-    long long qi = (long long)q;
-    if (qi & 1) s = -s;
-    return (float)s;
+    const float INV_PI = 0x1.45f306p-2f;
+    const float P1 = 3.125f, P2 = 0x1.1p-6f, P3 = -0x1.2aeef4p-17f;
+    if (!(fabsf(x) < 1048576.0f)) return NAN;
+    const float k  = rintf(x * INV_PI);
+    const float r  = ((x - k * P1) - k * P2) - k * P3;
+    const float r2 = r * r;
+    float p = -0x1.ae6456p-26f;       /* -1/11! */
+    p = p * r2 + 0x1.71de3ap-19f;     /*  1/9!  */
+    p = p * r2 + -0x1.a01a02p-13f;    /* -1/7!  */
+    p = p * r2 + 0x1.111112p-7f;      /*  1/5!  */
+    p = p * r2 + -0x1.555556p-3f;     /* -1/3!  */
+    float s = r + (r * r2) * p;
+    if ((int32_t)k & 1) s = -s;
+    return s;
 }
 
 static inline uint8_t unorm8(float v)

@@ -158,8 +158,18 @@ int prepare_trace(vrt_ctx *c, const float *cam, uint32_t w, uint32_t h, const vr
     p.n = (int)c->n;
     p.n_pow2_mask = (c->n & (c->n - 1)) == 0 ? (int)c->n - 1 : -1;
     p.max_steps = c->max_steps;
+    p.tile_log2h = 2;
+    p.need_cap = c->max_steps < 3u * c->n ? 1u : 0u;
+    for (int k = 0; k < 3; ++k) {
+        const int n = (int)c->n;
+        const int mid = (int)std::floor(cam[12 + k] / (float)VRT_CHUNK_SIZE) * VRT_CHUNK_SIZE + VRT_CHUNK_SIZE / 2;
+        p.lo[k] = mid - n / 2;
+        p.up[k] = mid + n / 2 - 1;
+        int r = p.lo[k] % n;
+        p.off[k] = r < 0 ? r + n : r;
+    }
+    { const char *v = std::getenv("VRT_TILE_LOG2H"); if (v) p.tile_log2h = (uint32_t)std::atoi(v) % 7u; }  // A/B only
     { const char *v = std::getenv("VRT_SKIP_VARIANT"); p.variant = v ? (uint32_t)std::atoi(v) : 0u; }  // A/B only
-    { const char *v = std::getenv("VRT_DEBUG_ITERS"); p.debug_iters = v ? (uint32_t)std::atoi(v) : 0u; }
     p.block = c->d_block;
     p.dist = c->dist_nonzero ? c->d_dist : nullptr;
     p.cells = c->d_cells; p.nc = (int)c->n / 4;

@@ -52,31 +52,25 @@ VRT_DEV int argmin3(float a, float b, float c)
     return idx;
 }
 
-// Canonical sine of the shading term (raytrace.glsl:130): double-precision reduction
-// against pi = HI + LO (HI has 33 significant bits, so q*HI is exact for |q| < 2^20),
-// odd Taylor polynomial through r^17, one rounding to float.
+// Canonical sine of the shading term (raytrace.glsl:130), binary32 throughout: k = rint(x/pi),
+// reduction against pi = P1 + P2 + P3 with P1 = 3.125 (k*P1 and x - k*P1 are exact for
+// |k| < 2^19), odd Taylor polynomial through r^11.  |error| < 3e-7 for |x| < 2^20.
 VRT_DEV float canon_sin(float x)
 {
-    const double INV_PI = 0x1.45f306dc9c883p-2;
-    const double PI_HI  = 0x1.921fb54400000p+1;
-    const double PI_LO  = 0x1.0b4611a626331p-33;
-    double xd = (double)x;
-    if (!(fabs(xd) < 1048576.0)) return __builtin_nanf("");
-    double q  = rint(xd * INV_PI);
-    double r  = (xd - q * PI_HI) - q * PI_LO;
-    double r2 = r * r;
-    double p  = 0x1.952c77030ad4ap-49;
-    p = p * r2 + -0x1.ae7f3e733b81fp-41;
-    p = p * r2 + 0x1.6124613a86d09p-33;
-    p = p * r2 + -0x1.ae64567f544e4p-26;
-    p = p * r2 + 0x1.71de3a556c734p-19;
-    p = p * r2 + -0x1.a01a01a01a01ap-13;
-    p = p * r2 + 0x1.1111111111111p-7;
-    p = p * r2 + -0x1.5555555555555p-3;
-    double s = r + (r * r2) * p;
-    long long qi = (long long)q;
-    if (qi & 1) s = -s;
-    return (float)s;
+    const float INV_PI = 0x1.45f306p-2f;
+    const float P1 = 3.125f, P2 = 0x1.1p-6f, P3 = -0x1.2aeef4p-17f;
+    if (!(fabsf(x) < 1048576.0f)) return __builtin_nanf("");
+    const float k  = rintf(x * INV_PI);
+    const float r  = ((x - k * P1) - k * P2) - k * P3;
+    const float r2 = r * r;
+    float p = -0x1.ae6456p-26f;
+    p = p * r2 + 0x1.71de3ap-19f;
+    p = p * r2 + -0x1.a01a02p-13f;
+    p = p * r2 + 0x1.111112p-7f;
+    p = p * r2 + -0x1.555556p-3f;
+    float s = r + (r * r2) * p;
+    if ((int)k & 1) s = -s;
+    return s;
 }
 
 // B8G8R8A8_UNORM store: clamp to [0,1] (NaN -> 0), round half up.

@@ -22,10 +22,14 @@ struct TraceParams {
     uint32_t w, h;         // frame size
     RowMap   rows;
     int32_t  n;            // voxels per axis
+    // loaded area of this camera (raytrace.glsl:19-24), computed once on the host:
+    // lo = floor(ro/32)*32 + 16 - n/2, up = lo + n - 1, off = rem_euclid(lo, n)
+    int32_t  lo[3], up[3], off[3];
     int32_t  n_pow2_mask;  // n-1 if n is a power of two, else -1
     uint32_t max_steps;
+    uint32_t tile_log2h;   // wave tile is (64 >> tile_log2h) x (1 << tile_log2h) pixels, 0..6
     uint32_t variant;      // selects an experimental kernel form in A/B measurements; 0 = default
-    uint32_t debug_iters;  // diagnostic: the steps plane receives the kernel's own loop count
+    uint32_t need_cap;     // max_steps can end a regular ray (max_steps < 3n): test it in the skip loop
     // world
     const void     *block;  // n^3 texels (u8 or u16), linear x fastest
     const uint16_t *dist;   // n^3 texels or nullptr (all zero)

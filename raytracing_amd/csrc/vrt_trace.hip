@@ -1,7 +1,7 @@
 // vrt_trace.hip -- primary-ray kernels for gfx950.
 //
-// One thread per pixel; a 256-thread workgroup covers a 16x16 pixel tile as four
-// wavefronts of 8x8 pixels, so the 64 rays of a wavefront stay spatially coherent.
+// One thread per pixel; a wavefront covers a small rectangle of pixels (8x8 by default), so
+// its 64 rays stay spatially coherent; a 256-thread workgroup stacks four such tiles.
 //
 //   k_trace_literal : one voxel per iteration, straight restatement of
 //                     raytrace.glsl:26-77 (reads the linear block / distance images).
@@ -43,14 +43,6 @@ template <typename T>
 VRT_DEV unsigned load_block(const TraceParams &P, int x, int y, int z)
 {
     return (unsigned)((const T *)P.block)[texel_index(P, x, y, z)];
-}
-
-// raytrace.glsl:19-24; lower = window minimum, upper = window minimum + n - 1.
-VRT_DEV void loaded_area(const TraceParams &P, float ro, int &lower, int &upper)
-{
-    int mid = wadd(wmul(f2i(floorf(ro / (float)kChunk)), kChunk), kChunk / 2);
-    lower   = wsub(mid, P.n / 2);
-    upper   = wsub(wadd(mid, P.n / 2), 1);
 }
 
 // ---------------------------------------------------------------------------
@@ -171,7 +163,7 @@ VRT_DEV void traverse_skip(const TraceParams &P, float rox, float roy, float roz
     const int  whix = wlox + (n - 3), whiy = wloy + (n - 3), whiz = wloz + (n - 3);
     const unsigned span = (unsigned)(n - 3);
     // texel of an anchor: u + off (mod n), off = rem_euclid(lower, n), a multiple of 4
-    const int  offx = rem_euclid(lox, n), offy = rem_euclid(loy, n), offz = rem_euclid(loz, n);
+    const int  offx = P.off[0], offy = P.off[1], offz = P.off[2];
     // byte of the record's distance word that belongs to this ray's octant
     const int  oct = (px ? 1 : 0) | (py ? 2 : 0) | (pz ? 4 : 0);
     const int  dshift = 8 * (oct & 3);
@@ -203,7 +195,7 @@ VRT_DEV void traverse_skip(const TraceParams &P, float rox, float roy, float roz
         locate();  // the start voxel's cell (the voxel itself is never tested)
     for (;;) {
         if ((unsigned)(wx - wlox) > span || (unsigned)(wy - wloy) > span || (unsigned)(wz - wloz) > span) break;
-        if (steps >= P.max_steps) { H.capped = 1; break; }
+        if (P.need_cap && steps >= P.max_steps) { H.capped = 1; break; }
         int   k;
         float tk;
         bool  moved_cell;
@@ -226,11 +218,13 @@ VRT_DEV void traverse_skip(const TraceParams &P, float rox, float roy, float roz
                 fwz = min((wz | 3) + r4, whiz);
             }
             // the box may not carry the ray past the step cap (only with tiny caps)
-            unit = steps + (unsigned)((fwx - wx) + (fwy - wy) + (fwz - wz) + 3) > P.max_steps;
+            if (P.need_cap) unit = steps + (unsigned)((fwx - wx) + (fwy - wy) + (fwz - wz) + 3) > P.max_steps;
         }
         if (unit) {
             // unit step (raytrace.glsl:45-50 with a zero distance)
-            iters += 0x10001u;  // diagnostic: high half counts unit steps
+#ifdef VRT_DIAG_ITERS
+            iters += 0x10001u;  // low half: loop iterations, high half: unit steps among them
+#endif
             const float tx = ((float)(wx + lnx + 1) - rnx) * inx;
             const float ty = ((float)(wy + lny + 1) - rny) * iny;
             const float tz = ((float)(wz + lnz + 1) - rnz) * inz;
@@ -241,7 +235,9 @@ VRT_DEV void traverse_skip(const TraceParams &P, float rox, float roy, float roz
             moved_cell = (wk & 3) == 0;
             steps += 1;
         } else {
+#ifdef VRT_DIAG_ITERS
             iters += 1u;
+#endif
             // exit planes = lower faces of the first anchors outside the box
             const float tx = ((float)(fwx + lnx + 1) - rnx) * inx;
             const float ty = ((float)(fwy + lny + 1) - rny) * iny;
@@ -301,11 +297,14 @@ VRT_DEV void traverse_skip(const TraceParams &P, float rox, float roy, float roz
 // ---------------------------------------------------------------------------
 // per-pixel prologue / epilogue shared by both kernels
 // ---------------------------------------------------------------------------
+// Wave tile = (64 >> tile_log2h) x (1 << tile_log2h) pixels; a workgroup stacks its four waves
+// vertically.  tile_log2h = 3 gives 8x8-pixel waves in a 8x32 block.
 VRT_DEV bool pixel_of_thread(const TraceParams &P, unsigned &col, unsigned &q, unsigned &row)
 {
     const unsigned tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    col = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-    q   = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const unsigned lh = P.tile_log2h, tw = 64u >> lh;
+    col = blockIdx.x * tw + (lane & (tw - 1));
+    q   = ((blockIdx.y * 4 + wave) << lh) + (lane >> (6 - lh));
     if (col >= P.w || q >= P.rows.rows) return false;
     if (P.rows.strip_h == 0) {
         row = P.rows.y0 + q;
@@ -343,9 +342,10 @@ VRT_DEV void finish_pixel(const TraceParams &P, unsigned gx, unsigned gy, size_t
     } else {
         r = g = b = 0.0f;
     }
-    const float dx = (float)gx - (float)(int)(P.w / 2);
-    const float dy = (float)gy - (float)(int)(P.h / 2);
-    if (sqrtf(dx * dx + dy * dy) < 1.2f) { r = 1.0f; g = 0.3f; b = 0.3f; a = 1.0f; }  // render.comp:10-12
+    // render.comp:10-12: length(vec2(gid) - vec2(size/2)) < 1.2.  The offsets are integers, so the
+    // squared length is an integer and sqrt(.) < 1.2 holds exactly when it is 0 or 1.
+    const int dx = (int)gx - (int)(P.w / 2), dy = (int)gy - (int)(P.h / 2);
+    if (dx * dx + dy * dy <= 1) { r = 1.0f; g = 0.3f; b = 0.3f; a = 1.0f; }
 
     if (P.bgra8) {
         const unsigned px = unorm8(b) | (unorm8(g) << 8) | (unorm8(r) << 16) | (unorm8(a) << 24);
@@ -353,7 +353,11 @@ VRT_DEV void finish_pixel(const TraceParams &P, unsigned gx, unsigned gy, size_t
     }
     if (P.voxel) { P.voxel[3 * i] = H.vx; P.voxel[3 * i + 1] = H.vy; P.voxel[3 * i + 2] = H.vz; }
     if (P.face) P.face[i] = H.hit ? 2 * H.k + (H.sk < 0 ? 1 : 0) : (H.capped ? -2 : -1);
-    if (P.steps) P.steps[i] = P.debug_iters ? H.iters : H.steps;
+#ifdef VRT_DIAG_ITERS
+    if (P.steps) P.steps[i] = H.iters;  // diagnostic build: the kernel's own loop count
+#else
+    if (P.steps) P.steps[i] = H.steps;
+#endif
     if (P.t) P.t[i] = H.t;
     if (P.hit_point) { P.hit_point[3 * i] = H.hx; P.hit_point[3 * i + 1] = H.hy; P.hit_point[3 * i + 2] = H.hz; }
     if (P.rgba) { P.rgba[4 * i] = r; P.rgba[4 * i + 1] = g; P.rgba[4 * i + 2] = b; P.rgba[4 * i + 3] = a; }
@@ -368,8 +372,8 @@ __global__ __launch_bounds__(256) void k_trace_literal(const TraceParams P)
     float rdx, rdy, rdz;
     raygen(P, gx, gy, rdx, rdy, rdz);
     const float rox = P.m[12], roy = P.m[13], roz = P.m[14];  // raytrace.glsl:16
-    int lox, loy, loz, upx, upy, upz;
-    loaded_area(P, rox, lox, upx); loaded_area(P, roy, loy, upy); loaded_area(P, roz, loz, upz);
+    // loaded area (raytrace.glsl:19-24), evaluated once per frame on the host
+    const int lox = P.lo[0], loy = P.lo[1], loz = P.lo[2], upx = P.up[0], upy = P.up[1], upz = P.up[2];
     RayHit H;
     traverse_literal<T, HAS_DIST>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
     finish_pixel(P, gx, gy, (size_t)q * P.w + col, H);
@@ -384,8 +388,8 @@ __global__ __launch_bounds__(256) void k_trace_skip(const TraceParams P)
     float rdx, rdy, rdz;
     raygen(P, gx, gy, rdx, rdy, rdz);
     const float rox = P.m[12], roy = P.m[13], roz = P.m[14];
-    int lox, loy, loz, upx, upy, upz;
-    loaded_area(P, rox, lox, upx); loaded_area(P, roy, loy, upy); loaded_area(P, roz, loz, upz);
+    // loaded area (raytrace.glsl:19-24), evaluated once per frame on the host
+    const int lox = P.lo[0], loy = P.lo[1], loz = P.lo[2], upx = P.up[0], upy = P.up[1], upz = P.up[2];
     RayHit H;
     traverse_skip<T>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
     finish_pixel(P, gx, gy, (size_t)q * P.w + col, H);
@@ -437,8 +441,8 @@ __global__ __launch_bounds__(256) void k_trace_secondary(const TraceParams P, ui
     float rdx, rdy, rdz;
     raygen(P, gx, gy, rdx, rdy, rdz);
     const float rox = P.m[12], roy = P.m[13], roz = P.m[14];
-    int lox, loy, loz, upx, upy, upz;
-    loaded_area(P, rox, lox, upx); loaded_area(P, roy, loy, upy); loaded_area(P, roz, loz, upz);
+    // loaded area (raytrace.glsl:19-24), evaluated once per frame on the host
+    const int lox = P.lo[0], loy = P.lo[1], loz = P.lo[2], upx = P.up[0], upy = P.up[1], upz = P.up[2];
     RayHit H;
     traverse_skip<T>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
     unsigned sh = 0, occ = 0, st = 0;
@@ -463,7 +467,11 @@ __global__ __launch_bounds__(256) void k_trace_secondary(const TraceParams P, ui
     if (sec_steps) sec_steps[i] = st;
 }
 
-static dim3 trace_grid(const TraceParams &p) { return dim3((p.w + 15) / 16, (p.rows.rows + 15) / 16, 1); }
+static dim3 trace_grid(const TraceParams &p)
+{
+    const unsigned tw = 64u >> p.tile_log2h, bh = 4u << p.tile_log2h;
+    return dim3((p.w + tw - 1) / tw, (p.rows.rows + bh - 1) / bh, 1);
+}
 
 hipError_t launch_trace_literal(const TraceParams &p, int voxel_bytes, hipStream_t s)
 {

@@ -228,9 +228,12 @@ def test_frame_row_mapping_against_single_rays():
 
 
 def test_canonical_sine_is_a_sine():
-    xs = np.arange(-4096, 4097, 2, dtype=np.float32)
+    xs = np.concatenate([np.arange(-4096, 4097, 2), np.arange(-2**20 + 2, 2**20, 2 * 9973)]).astype(np.float32)
     got = np.array([O.sin(x) for x in xs], np.float32)
-    assert np.abs(got - np.sin(xs.astype(np.float64))).max() < 6e-8
+    assert np.abs(got - np.sin(xs.astype(np.float64))).max() < 3e-7
+    xs = np.linspace(-7, 7, 2001).astype(np.float32)
+    got = np.array([O.sin(x) for x in xs], np.float32)
+    assert np.abs(got - np.sin(xs.astype(np.float64))).max() < 3e-7
     assert np.isnan(O.sin(np.float32("nan"))) and np.isnan(O.sin(np.float32("inf")))
 
 

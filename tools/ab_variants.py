@@ -19,7 +19,7 @@ frame = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
 ref = None
 times = {v: [] for v in variants}
 for v in variants:  # correctness of each variant against the first
-    os.environ["VRT_SKIP_VARIANT"] = v
+    os.environ[os.environ.get("AB_VAR", "VRT_SKIP_VARIANT")] = v
     out = g.trace(cam, W, H, outputs=("bgra8", "steps", "voxel", "face", "t"))
     if ref is None:
         ref = out
@@ -30,7 +30,7 @@ for v in variants:  # correctness of each variant against the first
             assert np.array_equal(a, b), f"variant {v} differs from {variants[0]} on {k}: {(a != b).sum()} elements"
 for r in range(rounds):
     for v in variants:
-        os.environ["VRT_SKIP_VARIANT"] = v
+        os.environ[os.environ.get("AB_VAR", "VRT_SKIP_VARIANT")] = v
         g.kernel_time_reset()
         for _ in range(20):
             g.trace_device(cam, W, H, 0, H, {"bgra8": frame.data_ptr()})

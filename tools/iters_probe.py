@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Diagnostic: per-pixel loop iterations of the trace kernel on the bench workload
-(VRT_DEBUG_ITERS=1 makes the steps plane carry the kernel's own loop count)."""
+"""Diagnostic: per-pixel loop iterations of the skip kernel on the bench workload.  Needs the
+diagnostic library build, whose steps plane carries the kernel's own loop count:
+    make -C raytracing_amd/csrc clean && make -C raytracing_amd/csrc EXTRA=-DVRT_DIAG_ITERS
+(rebuild without EXTRA afterwards)."""
 import os, sys
-os.environ["VRT_DEBUG_ITERS"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from raytracing_amd import GraphicsCore, VOXEL_PACKED_U8, TRACE_SKIP, scenes

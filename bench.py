@@ -74,6 +74,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--mode", choices=["auto", "skip", "literal"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo: rehearsal of the multi-rank path on hosts without one GPU per rank "
+                         "(frames are gathered through host memory; not a measurement)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -82,9 +85,14 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if args.backend == "gloo":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     mode = {"auto": TRACE_AUTO, "skip": TRACE_SKIP, "literal": TRACE_LITERAL}[args.mode]
     core = GraphicsCore(width=W, height=H, device=local_rank, grid_n=N_GRID, voxel_format=VOXEL_PACKED_U8,
@@ -99,31 +107,54 @@ def main():
     build_s = time.perf_counter() - t0
 
     stream = torch.cuda.ExternalStream(core.stream(), device=torch.device("cuda", local_rank))
-    frame = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+    host = args.backend == "gloo"
+    # two frame buffers: the gather of frame k overlaps the trace of frame k+1
+    frames = [torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
     steps_t = torch.zeros((H, W), dtype=torch.int32, device="cuda")
-    gathered = [torch.zeros_like(frame) for _ in range(world)] if (world > 1 and rank == 0) else None
+    gathered = [None, None]
+    if world > 1 and rank == 0:
+        gathered = [[torch.zeros((H, W, 4), dtype=torch.uint8, device="cpu" if host else "cuda") for _ in range(world)]
+                    for _ in range(2)]
+    pending = [None, None]
     torch.cuda.synchronize()
 
     # untimed: step counts of this frame -> algorithmic bytes
-    core.trace_device(cam, W, H, 0, H, {"bgra8": frame.data_ptr(), "steps": steps_t.data_ptr()})
+    core.trace_device(cam, W, H, 0, H, {"bgra8": frames[0].data_ptr(), "steps": steps_t.data_ptr()})
     core.sync()
     steps_np = steps_t.cpu().numpy().view(np.uint32)
     sum_steps = int(steps_np.astype(np.int64).sum())
     alg_bytes = sum_steps * 1 + W * H * 4
 
-    ptrs = {"bgra8": frame.data_ptr()}
+    counter = [0]
 
     def step():
-        core.trace_device(cam, W, H, 0, H, ptrs)
-        if world > 1:
+        b = counter[0] & 1
+        counter[0] += 1
+        if world > 1 and not host:
             with torch.cuda.stream(stream):
-                dist.gather(frame, gathered, dst=0)
+                if pending[b] is not None:
+                    pending[b].wait()                # the trace below may overwrite frames[b] only after its gather
+                core.trace_device(cam, W, H, 0, H, {"bgra8": frames[b].data_ptr()})
+                # RCCL gather to rank 0, ordered behind the trace on the context's stream
+                pending[b] = dist.gather(frames[b], gathered[b], dst=0, async_op=True)
+        elif world > 1:
+            core.trace_device(cam, W, H, 0, H, {"bgra8": frames[b].data_ptr()})
+            core.sync()
+            dist.gather(frames[b].cpu(), gathered[b], dst=0)
+        else:
+            core.trace_device(cam, W, H, 0, H, {"bgra8": frames[b].data_ptr()})
 
     def fence():
-        if world > 1:
-            dist.barrier()
+        for b in range(2):
+            if pending[b] is not None:
+                with torch.cuda.stream(stream):
+                    pending[b].wait()
+                pending[b] = None
         core.sync()
         torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -137,7 +168,7 @@ def main():
     kern_ms, launches = core.kernel_time()
 
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if host else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

@@ -155,6 +155,7 @@ int prepare_trace(vrt_ctx *c, const float *cam, uint32_t w, uint32_t h, const vr
     std::memset(&p, 0, sizeof p);
     std::memcpy(p.m, cam, sizeof p.m);
     p.w = w; p.h = h; p.rows = rows;
+    p.ncy_off = (float)h / (float)w * 0.5f;
     p.n = (int)c->n;
     p.n_pow2_mask = (c->n & (c->n - 1)) == 0 ? (int)c->n - 1 : -1;
     p.max_steps = c->max_steps;

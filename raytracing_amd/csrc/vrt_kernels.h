@@ -20,6 +20,7 @@ struct RowMap {
 struct TraceParams {
     float    m[16];        // camera transform, column major
     uint32_t w, h;         // frame size
+    float    ncy_off;      // (float(h) / float(w)) * 0.5f of raytrace.glsl:121, evaluated on the host
     RowMap   rows;
     int32_t  n;            // voxels per axis
     // loaded area of this camera (raytrace.glsl:19-24), computed once on the host:

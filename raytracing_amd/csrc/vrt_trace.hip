@@ -178,10 +178,14 @@ VRT_DEV void traverse_skip(const TraceParams &P, float rox, float roy, float roz
     unsigned info = 0;       // empty cells: column-top pyramid entry (level | layers << 8)
     uint64_t cur_mask = 0;   // non-empty cells: occupancy
     int qx = 0, qy = 0, qz = 0;  // texel of the anchor at the last cell lookup
+    const bool pow2 = P.n_pow2_mask >= 0;  // wave uniform
     auto locate = [&]() {
-        qx = (wx ^ smx) + offx; qx -= qx >= n ? n : 0;
-        qy = (wy ^ smy) + offy; qy -= qy >= n ? n : 0;
-        qz = (wz ^ smz) + offz; qz -= qz >= n ? n : 0;
+        qx = (wx ^ smx) + offx; qy = (wy ^ smy) + offy; qz = (wz ^ smz) + offz;
+        if (pow2) {
+            qx &= P.n_pow2_mask; qy &= P.n_pow2_mask; qz &= P.n_pow2_mask;
+        } else {
+            qx -= qx >= n ? n : 0; qy -= qy >= n ? n : 0; qz -= qz >= n ? n : 0;
+        }
         const int cell = ((qz >> 2) * nc + (qy >> 2)) * nc + (qx >> 2);
         if (cell != cur_cell) {
             const uint4 r = P.cells[cell];
@@ -207,7 +211,7 @@ VRT_DEV void traverse_skip(const TraceParams &P, float rox, float roy, float roz
                 // column-top pyramid: the aligned block of 2^lvl x 2^lvl cell columns around this
                 // one is empty from layer (info >> 8) up to the top of the window
                 const int m4 = (4 << lvl) - 1;
-                locate();  // texel of the current anchor (a no-op load: the cell is unchanged)
+                if (P.need_cap) locate();  // qx, qz may be stale after capped unit steps in an empty cell
                 fwx = min(wx + ((qx ^ ~smx) & m4), whix);
                 fwz = min(wz + ((qz ^ ~smz) & m4), whiz);
                 fwy = py ? whiy : min(~(int)((info >> 8) << 2), whiy);
@@ -218,25 +222,16 @@ VRT_DEV void traverse_skip(const TraceParams &P, float rox, float roy, float roz
                 fwz = min((wz | 3) + r4, whiz);
             }
             // the box may not carry the ray past the step cap (only with tiny caps)
-            if (P.need_cap) unit = steps + (unsigned)((fwx - wx) + (fwy - wy) + (fwz - wz) + 3) > P.max_steps;
+            if (P.need_cap && steps + (unsigned)((fwx - wx) + (fwy - wy) + (fwz - wz) + 3) > P.max_steps) {
+                unit = true; fwx = wx; fwy = wy; fwz = wz;
+            }
         }
-        if (unit) {
-            // unit step (raytrace.glsl:45-50 with a zero distance)
+        // The box code below also performs a unit step when the box is the single voxel
+        // (fw = w), so a wavefront runs it whenever any of its lanes has a box to cross and
+        // the cheaper unit-step code only when none has.
+        if (__any(unit ? 0 : 1)) {
 #ifdef VRT_DIAG_ITERS
-            iters += 0x10001u;  // low half: loop iterations, high half: unit steps among them
-#endif
-            const float tx = ((float)(wx + lnx + 1) - rnx) * inx;
-            const float ty = ((float)(wy + lny + 1) - rny) * iny;
-            const float tz = ((float)(wz + lnz + 1) - rnz) * inz;
-            k  = argmin3(tx, ty, tz);
-            tk = k == 0 ? tx : (k == 1 ? ty : tz);
-            wx += k == 0 ? 1 : 0; wy += k == 1 ? 1 : 0; wz += k == 2 ? 1 : 0;
-            const int wk = k == 0 ? wx : (k == 1 ? wy : wz);
-            moved_cell = (wk & 3) == 0;
-            steps += 1;
-        } else {
-#ifdef VRT_DIAG_ITERS
-            iters += 1u;
+            iters += unit ? 0x10001u : 1u;  // low half: loop iterations, high half: unit steps among them
 #endif
             // exit planes = lower faces of the first anchors outside the box
             const float tx = ((float)(fwx + lnx + 1) - rnx) * inx;
@@ -252,7 +247,7 @@ VRT_DEV void traverse_skip(const TraceParams &P, float rox, float roy, float roz
             const bool nearx = fabsf(psx - i0x) <= 0x1.0p-20f * ((rtx + fabsf(psx)) + 1.0f);
             const bool neary = fabsf(psy - i0y) <= 0x1.0p-20f * ((rty + fabsf(psy)) + 1.0f);
             const bool nearz = fabsf(psz - i0z) <= 0x1.0p-20f * ((rtz + fabsf(psz)) + 1.0f);
-            if (__any((nearx || neary || nearz) ? 1 : 0)) {
+            if (__any((!unit && (nearx || neary || nearz)) ? 1 : 0)) {
                 // a plane within the margin: has the reference crossed it before the exit event?
                 // axis j's events sort before the exit event of axis k on ties iff j < k
                 const float ttx = (i0x - rnx) * inx, tty = (i0y - rny) * iny, ttz = (i0z - rnz) * inz;
@@ -268,7 +263,22 @@ VRT_DEV void traverse_skip(const TraceParams &P, float rox, float roy, float roz
             vz = k == 2 ? fwz + 1 : min(max(vz, wz), fwz);
             steps += (unsigned)((vx - wx) + (vy - wy) + (vz - wz));
             wx = vx; wy = vy; wz = vz;
-            moved_cell = true;
+            const int wk = k == 0 ? wx : (k == 1 ? wy : wz);
+            moved_cell = !unit || (wk & 3) == 0;
+        } else {
+            // unit step (raytrace.glsl:45-50 with a zero distance)
+#ifdef VRT_DIAG_ITERS
+            iters += 0x10001u;
+#endif
+            const float tx = ((float)(wx + lnx + 1) - rnx) * inx;
+            const float ty = ((float)(wy + lny + 1) - rny) * iny;
+            const float tz = ((float)(wz + lnz + 1) - rnz) * inz;
+            k  = argmin3(tx, ty, tz);
+            tk = k == 0 ? tx : (k == 1 ? ty : tz);
+            wx += k == 0 ? 1 : 0; wy += k == 1 ? 1 : 0; wz += k == 2 ? 1 : 0;
+            const int wk = k == 0 ? wx : (k == 1 ? wy : wz);
+            moved_cell = (wk & 3) == 0;
+            steps += 1;
         }
         // test the voxel just entered
         if (moved_cell) locate();
@@ -319,7 +329,7 @@ VRT_DEV void raygen(const TraceParams &P, unsigned gx, unsigned gy, float &rdx, 
 {
     const float fw = (float)P.w, fh = (float)P.h;
     const float ncx = (float)gx / fw - 0.5f;
-    const float ncy = (float)gy / fh - (fh / fw * 0.5f);
+    const float ncy = (float)gy / fh - P.ncy_off;
     const float *m = P.m;
     const float d0 = ((ncx * m[0] + ncy * m[1]) + 1.0f * m[2]) + 1.0f * m[3];
     const float d1 = ((ncx * m[4] + ncy * m[5]) + 1.0f * m[6]) + 1.0f * m[7];

@@ -219,3 +219,16 @@ def test_error_paths():
             g.trace(cam, 64, 48, 10, 5)
         with pytest.raises(VrtError):
             g.trace(cam, 0, 48)
+
+
+def test_world_uploaded_from_device_memory(scene160):
+    import torch
+    cam = scenes.cam16(scenes.pose_b())
+    want = O.trace(O.World(scene160), cam, 160, 120)
+    dev = torch.from_numpy(scene160.view(np.int16)).cuda()
+    torch.cuda.synchronize()
+    with GraphicsCore(grid_n=160, trace_mode=TRACE_SKIP) as g:
+        g.upload_world_device(dev.data_ptr())
+        got = g.trace(cam, 160, 120)
+        assert np.array_equal(g.download_world(), scene160)
+    assert_planes_equal(got, want, "device upload")

@@ -212,8 +212,9 @@ VRT_DEV void traverse_skip(const TraceParams &P, float rox, float roy, float roz
                 // one is empty from layer (info >> 8) up to the top of the window
                 const int m4 = (4 << lvl) - 1;
                 if (P.need_cap) locate();  // qx, qz may be stale after capped unit steps in an empty cell
-                fwx = min(wx + ((qx ^ ~smx) & m4), whix);
-                fwz = min(wz + ((qz ^ ~smz) & m4), whiz);
+                // (a block as wide as the torus has no edge: the seam is not a boundary)
+                fwx = m4 >= n - 1 ? whix : min(wx + ((qx ^ ~smx) & m4), whix);
+                fwz = m4 >= n - 1 ? whiz : min(wz + ((qz ^ ~smz) & m4), whiz);
                 fwy = py ? whiy : min(~(int)((info >> 8) << 2), whiy);
             } else {
                 const int r4 = (d - 1) << 2;

@@ -232,3 +232,54 @@ def test_world_uploaded_from_device_memory(scene160):
         got = g.trace(cam, 160, 120)
         assert np.array_equal(g.download_world(), scene160)
     assert_planes_equal(got, want, "device upload")
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_far_from_the_origin(mode):
+    # camera up to 2^20 voxels out: float spacing reaches 1/8 voxel, the skip kernel's margin
+    # test then sends almost every box exit through the exact plane comparison
+    rng = np.random.default_rng(21)
+    n = 64
+    block = ((rng.random((n, n, n)) < 0.004) * rng.integers(1, 250, (n, n, n))).astype(np.uint8)
+    world = O.World(block)
+    with core_for(block, mode) as g:
+        for pos in [(500000.3, 40.2, -700000.7), (-1048000.5, 1047000.25, 3.5), (65536.0, -65536.0, 131072.0),
+                    (9999.99, 123456.78, -1000001.1)]:
+            for yaw, pitch in [(0.6, -0.35), (2.9, 1.1)]:
+                cam = scenes.cam16(Player.at(pos, yaw, pitch))
+                want = O.trace(world, cam, 96, 64)
+                got = g.trace(cam, 96, 64)
+                assert_planes_equal(got, want, f"pos {pos} yaw {yaw}")
+
+
+def test_fuzz_many_small_worlds():
+    # seeded sweep: grid sizes (powers of two and not), voxel formats, densities from empty to
+    # dense, height-field and random worlds, cameras inside / outside / on the window edge
+    rng = np.random.default_rng(2024)
+    for case in range(48):
+        n = int(rng.choice([8, 16, 24, 32, 40, 64, 96, 128]))
+        dtype = np.uint8 if rng.random() < 0.5 else np.uint16
+        kind = case % 3
+        if kind == 0:
+            block = ((rng.random((n, n, n)) < rng.choice([0.0005, 0.01, 0.2])) * rng.integers(1, 250, (n, n, n))).astype(dtype)
+        elif kind == 1:  # height field with random heights
+            hmap = rng.integers(0, max(2, n // 3), (n, n))
+            block = (np.arange(n)[None, :, None] < hmap[:, None, :]).astype(dtype) * 7
+        else:            # slabs and pillars
+            block = np.zeros((n, n, n), dtype)
+            block[:, : max(1, n // 8), :] = 1
+            for _ in range(6):
+                x, z = rng.integers(0, n, 2)
+                block[z, :, x] = 2
+        world = O.World(block)
+        fmt_mode = TRACE_SKIP
+        with core_for(block, fmt_mode) as g:
+            for _ in range(3):
+                pos = rng.uniform(-1.5 * n, 1.5 * n, 3)
+                if rng.random() < 0.3:
+                    pos = np.round(pos / 4) * 4          # on cell boundaries
+                cam = scenes.cam16(Player.at(pos, rng.uniform(-3.2, 3.2), rng.uniform(-1.6, 1.6)))
+                w, h = int(rng.integers(17, 70)), int(rng.integers(9, 40))
+                want = O.trace(world, cam, w, h)
+                got = g.trace(cam, w, h)
+                assert_planes_equal(got, want, f"case {case} n {n} pos {pos}")

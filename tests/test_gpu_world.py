@@ -57,3 +57,23 @@ def test_generated_world_traces_like_uploaded_world():
         if a.dtype == np.float32:
             a, b = a.view(np.uint32), b.view(np.uint32)
         assert np.array_equal(a, b), k
+
+
+def test_generator_far_from_the_surface_matches_oracle():
+    # the kernel skips the noise where |y| > 128 (its sign cannot matter there); the oracle does not
+    n = 512
+    wmin = (-100, -250, 40)
+    with GraphicsCore(grid_n=n, voxel_format=VOXEL_PACKED_U8) as g:
+        g.generate_window(wmin)
+        got = g.download_world()
+    rng = np.random.default_rng(5)
+    import pyref
+    ys = np.concatenate([np.arange(-250, -120), np.arange(120, 262)])
+    for y in ys[::3]:
+        for _ in range(4):
+            x = int(rng.integers(wmin[0], wmin[0] + n)); z = int(rng.integers(wmin[2], wmin[2] + n))
+            noise = float(O.snoise(np.float32(x) * np.float32(0.015), np.float32(y) * np.float32(0.015), np.float32(z) * np.float32(0.015)))
+            want = 1 if np.float32(np.float32(noise) * np.float32(6.0)) - np.float32(y) > 0 else 0
+            assert got[z % n, y % n, x % n] == want, (x, y, z)
+    # whole layers: solid below, air above
+    assert got[:, (-200) % n, :].all() and not got[:, 200 % n, :].any()

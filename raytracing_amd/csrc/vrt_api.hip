@@ -11,7 +11,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <new>
+#include <vector>
 
 namespace {
 
@@ -57,6 +59,11 @@ struct vrt_ctx {
     int         pyr_offcy    = -1;       // vertical window offset (cells) the pyramid entries were built for
     bool        skip_valid   = false;
     uint32_t   *d_flag       = nullptr;
+    // dispatch-order feedback of the skip kernels (vrt::RowSched)
+    uint32_t   *d_sched      = nullptr;       // start[2] | row_longest[2][256] | cost[2][kSchedCapacity]
+    uint32_t    sched_gen    = 0;             // generation of the last skip launch, 1..4095
+    uint32_t    sched_same   = 0;             // consecutive launches of this shape before the next one
+    uint64_t    sched_sig[4] = {0, 0, 0, 0};  // shape of the last launch; [0] == 0: none
     // staging for host-resident outputs
     void       *d_stage      = nullptr;
     size_t      stage_bytes  = 0;
@@ -121,6 +128,90 @@ int window_offcy(const vrt_ctx *c, float y)
 }
 
 struct Plane { size_t off, bytes; void *host; };
+
+constexpr uint32_t kSchedRows = 256;  // = SCHED_MAX_ROWS of the kernels
+
+// Packed row (of this launch) on which the central ray is horizontal: the rows with the longest rays
+// lie just under it, so a launch is only comparable with the previous one if it has not moved much.
+uint32_t horizon_packed_row(const float *m, uint32_t w, uint32_t h, const vrt::RowMap &rows)
+{
+    if (rows.rows == 0) return 0;
+    // raytrace.glsl:120-123 at the centre column: rd.y ~ ncy*m[5] + m[6] + m[7], ncy = gy/h - h/(2w), row = h - gy
+    float row = (float)h * 0.5f;
+    if (m[5] != 0.0f) {
+        const float ncy = -(m[6] + m[7]) / m[5];
+        row = (float)h - (ncy + (float)h / (float)w * 0.5f) * (float)h;
+    }
+    if (!(row > 0.0f)) row = 0.0f;                  // also catches NaN
+    if (row > (float)(h - 1)) row = (float)(h - 1);
+    const uint32_t r = (uint32_t)row;
+    uint32_t q;
+    if (rows.strip_h == 0) {
+        q = r <= rows.y0 ? 0u : r - rows.y0;
+    } else {
+        q = r / (rows.strip_h * rows.parts) * rows.strip_h;
+    }
+    return q < rows.rows ? q : rows.rows - 1;
+}
+
+constexpr uint32_t kSchedCapacity = 262144;  // wavefronts per launch the feedback covers (1080p: 32640, 4K: 129600)
+constexpr size_t kSchedHead = 2 + 2 * kSchedRows;
+constexpr size_t kSchedBytes = (kSchedHead + 2 * (size_t)kSchedCapacity) * sizeof(uint32_t);
+
+// Fills p.sched for a skip-kernel launch (kind 1: primary, 2: primary + secondary).  The start row
+// planned by the previous launch from the times of the launch before it is used when both had this
+// launch's kernel, frame, rows and (to a workgroup row) horizon; either way this launch measures.
+int attach_row_sched(vrt_ctx *c, vrt::TraceParams &p, uint32_t kind)
+{
+    p.sched = vrt::RowSched{};
+    p.sched.fixed_start = -1;
+    { const char *v = std::getenv("VRT_ROW_BLOCK0"); if (v && v[0] != 'x') { p.sched.fixed_start = std::atoi(v); c->sched_sig[0] = 0; return VRT_OK; } }  // A/B only
+    const uint32_t block_h = 4u << p.tile_log2h;
+    const uint32_t grid_y = (p.rows.rows + block_h - 1) / block_h;
+    const char *off = std::getenv("VRT_NO_ROW_ORDER");  // "1": rows top to bottom, for A/B measurements
+    const uint32_t grid_x = (p.w + (64u >> p.tile_log2h) - 1) / (64u >> p.tile_log2h);
+    if (!c->d_sched || grid_y == 0 || grid_y > kSchedRows || (uint64_t)grid_x * grid_y * 4 > kSchedCapacity || (off && off[0] == '1')) {
+        c->sched_sig[0] = 0;
+        return VRT_OK;
+    }
+    const uint64_t sig[4] = {
+        ((uint64_t)kind << 56) | ((uint64_t)p.tile_log2h << 48) | ((uint64_t)p.w << 24) | (uint64_t)p.h,
+        ((uint64_t)p.rows.y0 << 32) | (uint64_t)p.rows.rows,
+        ((uint64_t)p.rows.strip_h << 40) | ((uint64_t)p.rows.part << 20) | (uint64_t)p.rows.parts,
+        (uint64_t)(horizon_packed_row(p.m, p.w, p.h, p.rows) / block_h)};
+    if (std::getenv("VRT_SCHED_DEBUG") && c->sched_gen > 0) {  // diagnostic: what the last launch measured
+        std::vector<uint32_t> hbuf(kSchedHead + 2 * (size_t)kSchedCapacity);
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemcpy(hbuf.data(), c->d_sched, kSchedBytes, hipMemcpyDeviceToHost));
+        const uint32_t g = c->sched_gen;
+        std::fprintf(stderr, "[sched] gen %u start[0]=%u/%u start[1]=%u/%u rows:", g, hbuf[0] >> 16, hbuf[0] & 0xffff,
+                     hbuf[1] >> 16, hbuf[1] & 0xffff);
+        for (uint32_t r = 0; r < grid_y; ++r) {
+            uint32_t m = 0;
+            for (uint32_t x = 0; x < grid_x * 4; ++x) {
+                const uint32_t v = hbuf[kSchedHead + (size_t)(g & 1) * kSchedCapacity + r * grid_x * 4 + x];
+                if ((v >> 20) == g) m = std::max(m, v & 0xfffffu);
+            }
+            std::fprintf(stderr, " %u", m);
+        }
+        std::fprintf(stderr, "\n");
+    }
+    c->sched_same = std::memcmp(sig, c->sched_sig, sizeof sig) == 0 ? c->sched_same + 1 : 0;
+    if (c->sched_gen >= 4095u) {  // the tags are 12 bits wide: start over with clean slots
+        HIP_TRY(hipMemsetAsync(c->d_sched, 0, kSchedBytes, c->stream));
+        c->sched_gen = 0;
+        c->sched_same = 0;
+    }
+    c->sched_gen += 1;
+    p.sched.start = c->d_sched;
+    p.sched.row_longest = c->d_sched + 2;
+    p.sched.cost = c->d_sched + kSchedHead;
+    p.sched.capacity = kSchedCapacity;
+    p.sched.generation = c->sched_gen;
+    p.sched.use_order = c->sched_same >= 3 ? 1u : 0u;
+    std::memcpy(c->sched_sig, sig, sizeof sig);
+    return VRT_OK;
+}
 
 // argument checks, kernel choice and the parameter block shared by every trace entry point
 int prepare_trace(vrt_ctx *c, const float *cam, uint32_t w, uint32_t h, const vrt::RowMap &rows, bool need_skip,
@@ -216,6 +307,7 @@ int do_trace(vrt_ctx *c, const float *cam, uint32_t w, uint32_t h, const vrt::Ro
     if (c->ev_pending == kEventRing) { int rc = drain_events(c); if (rc != VRT_OK) return rc; }
     const int e = c->ev_pending;
     HIP_TRY(hipEventRecord(c->ev0[e], c->stream));
+    if (use_skip) { int rc = attach_row_sched(c, p, 1); if (rc != VRT_OK) return rc; }
     if (use_skip) { HIP_TRY(vrt::launch_trace_skip(p, c->voxel_bytes, c->stream)); c->last_kernel = "skip"; }
     else          { HIP_TRY(vrt::launch_trace_literal(p, c->voxel_bytes, c->stream)); c->last_kernel = "literal"; }
     HIP_TRY(hipEventRecord(c->ev1[e], c->stream));
@@ -272,6 +364,10 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out)
     for (int i = 0; i < kEventRing; ++i) { TRY_OR_BAIL(hipEventCreate(&c->ev0[i])); TRY_OR_BAIL(hipEventCreate(&c->ev1[i])); }
     TRY_OR_BAIL(hipMalloc(&c->d_block, texels(c) * (size_t)c->voxel_bytes));
     TRY_OR_BAIL(hipMalloc(&c->d_flag, sizeof(uint32_t)));
+    {
+        TRY_OR_BAIL(hipMalloc(&c->d_sched, kSchedBytes));
+        TRY_OR_BAIL(hipMemsetAsync(c->d_sched, 0, kSchedBytes, c->stream));
+    }
 #undef TRY_OR_BAIL
     *out = c;
     return VRT_OK;
@@ -286,7 +382,7 @@ int vrt_destroy(vrt_ctx *c)
         if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]);
         if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]);
     }
-    void *bufs[] = {c->d_block, c->d_dist, c->d_cells, c->d_tops, c->d_flag, c->d_stage};
+    void *bufs[] = {c->d_block, c->d_dist, c->d_cells, c->d_tops, c->d_flag, c->d_sched, c->d_stage};
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -393,6 +489,7 @@ int vrt_trace_secondary(vrt_ctx *c, const float cam[16], uint32_t w, uint32_t h,
     if (c->ev_pending == kEventRing) { int rc = drain_events(c); if (rc != VRT_OK) return rc; }
     const int e = c->ev_pending;
     HIP_TRY(hipEventRecord(c->ev0[e], c->stream));
+    { int rc = attach_row_sched(c, p, 2); if (rc != VRT_OK) return rc; }
     HIP_TRY(vrt::launch_trace_secondary(p, c->voxel_bytes, (uint8_t *)dev[0], (uint8_t *)dev[1], (uint32_t *)dev[2], c->stream));
     c->last_kernel = "secondary";
     HIP_TRY(hipEventRecord(c->ev1[e], c->stream));

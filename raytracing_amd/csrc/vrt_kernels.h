@@ -17,6 +17,24 @@ struct RowMap {
     uint32_t part, parts;
 };
 
+// Dispatch-order feedback of the skip kernels.  Launch g records the work of each of its wavefronts
+// (trips of the traversal loop); launch g + 1 reduces them to the longest per workgroup row; launch g + 2 derives the row
+// at which launch g + 3 starts (the topmost row that is not cheap); rows then run from there to the
+// bottom and on from the top.
+//   cost[g & 1][(row * grid_x + column) * 4 + wave] = g << 20 | work + 1               by launch g
+//   row_longest[g & 1][row]                         = g << 20 | work, of launch g - 1   by launch g
+//   start[g & 1]                                    = g << 16 | row                         by launch g - 1
+// The generation tags make stale entries read as "nothing known".
+struct RowSched {
+    uint32_t *cost;         // [2][capacity]; null = feature off
+    uint32_t *row_longest;  // [2][256]
+    uint32_t *start;        // [2]
+    uint32_t  capacity;     // wavefronts per half of `cost`
+    uint32_t  generation;   // g of this launch, 1..4095
+    uint32_t  use_order;    // 0: earlier launches do not describe this one, run rows top to bottom
+    int32_t   fixed_start;  // >= 0: start row given by the host (A/B measurements only)
+};
+
 struct TraceParams {
     float    m[16];        // camera transform, column major
     uint32_t w, h;         // frame size
@@ -31,6 +49,7 @@ struct TraceParams {
     uint32_t tile_log2h;   // wave tile is (64 >> tile_log2h) x (1 << tile_log2h) pixels, 0..6
     uint32_t variant;      // selects an experimental kernel form in A/B measurements; 0 = default
     uint32_t need_cap;     // max_steps can end a regular ray (max_steps < 3n): test it in the skip loop
+    RowSched sched;
     // world
     const void     *block;  // n^3 texels (u8 or u16), linear x fastest
     const uint16_t *dist;   // n^3 texels or nullptr (all zero)

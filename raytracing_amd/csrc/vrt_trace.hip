@@ -25,6 +25,7 @@ struct RayHit {
     int      sk;     // s11 of that axis
     unsigned steps;
     unsigned iters;  // iterations of the kernel's own loop (diagnostic)
+    unsigned work;   // trips of the two-phase loop this lane was live for (0 on the other paths)
     unsigned block_id;
     float    t, hx, hy, hz;
 };
@@ -97,7 +98,7 @@ VRT_DEV void traverse_literal(const TraceParams &P, float rox, float roy, float 
         cpy = wadd(wadd(ay, s01y), wmul(s11y, fd));
         cpz = wadd(wadd(az, s01z), wmul(s11z, fd));
     }
-    H.vx = ax; H.vy = ay; H.vz = az; H.steps = steps; H.iters = steps;
+    H.vx = ax; H.vy = ay; H.vz = az; H.steps = steps; H.iters = steps; H.work = 0;
     if (!H.hit) { H.t = -1.0f; H.hx = H.hy = H.hz = 0.0f; }
 }
 
@@ -301,21 +302,209 @@ VRT_DEV void traverse_skip(const TraceParams &P, float rox, float roy, float roz
         }
     }
     H.vx = (wx ^ smx) + lox; H.vy = (wy ^ smy) + loy; H.vz = (wz ^ smz) + loz;
-    H.steps = steps; H.iters = iters;
+    H.steps = steps; H.iters = iters; H.work = 0;
     if (!H.hit) { H.t = -1.0f; H.hx = H.hy = H.hz = 0.0f; }
+}
+
+// ---------------------------------------------------------------------------
+// exact empty-space skipping, two-phase loop (the form the kernels run unless the caller asked
+// for a step cap below 3n, which only traverse_skip above implements)
+// ---------------------------------------------------------------------------
+// Same boxes, same arithmetic and therefore the same visit order as traverse_skip, arranged
+// so that a wavefront does not pay for the box algebra on every voxel of a non-empty cell.
+// Each trip of the outer loop has two phases:
+//   A  lanes standing in an empty cell cross their box (one exact multi-voxel step) and look
+//      up the cell they land in;
+//   B  lanes standing in a non-empty cell take up to four unit steps (the reference's own
+//      step) against the 64-bit occupancy mask held in registers: about a quarter of the
+//      instructions of phase A each and no memory access until the walk leaves the cell.  The
+//      bound keeps a long walk of one lane from stalling the boxes of the other lanes.
+// Every step moves towards + in the mirrored frame, so only the stepped axis can leave the
+// window and only its upper bound needs a test; the voxel just entered is tested for a hit
+// before that, as the reference does (raytrace.glsl:52 comes before the next :43).
+template <typename T, bool POW2>
+VRT_DEV void traverse_cells(const TraceParams &P, float rox, float roy, float roz, float rdx, float rdy,
+                            float rdz, int lox, int loy, int loz, int upx, int upy, int upz, RayHit &H)
+{
+    const float invx = 1.0f / rdx, invy = 1.0f / rdy, invz = 1.0f / rdz;
+    const float big = 0x1.0p100f;
+    const bool regular = (rdx != 0.0f) && (rdy != 0.0f) && (rdz != 0.0f) && (fabsf(invx) < big) &&
+                         (fabsf(invy) < big) && (fabsf(invz) < big);
+    if (!regular) {
+        traverse_literal<T, false>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
+        return;
+    }
+    const int n = P.n, nc = P.nc;
+    const bool px = rdx > 0.0f, py = rdy > 0.0f, pz = rdz > 0.0f;
+    const int  smx = px ? 0 : -1, smy = py ? 0 : -1, smz = pz ? 0 : -1;
+    const float rnx = px ? rox : -rox, rny = py ? roy : -roy, rnz = pz ? roz : -roz;
+    const float dnx = fabsf(rdx), dny = fabsf(rdy), dnz = fabsf(rdz);
+    const float inx = fabsf(invx), iny = fabsf(invy), inz = fabsf(invz);
+    const int  lnx = px ? lox : -lox, lny = py ? loy : -loy, lnz = pz ? loz : -loz;
+    const int  wlox = px ? 0 : 1 - n, wloy = py ? 0 : 1 - n, wloz = pz ? 0 : 1 - n;
+    const int  whix = wlox + (n - 3), whiy = wloy + (n - 3), whiz = wloz + (n - 3);
+    const unsigned span = (unsigned)(n - 3);
+    const int  offx = P.off[0], offy = P.off[1], offz = P.off[2];
+    const int  oct = (px ? 1 : 0) | (py ? 2 : 0) | (pz ? 4 : 0);
+    const int  dshift = 8 * (oct & 3);
+    const bool dhigh = oct >= 4;
+    // change of the mask bit index (z*16 + y*4 + x of the unmirrored voxel) per unit step
+    const int  dbx = px ? 1 : -1, dby = py ? 4 : -4, dbz = pz ? 16 : -16;
+
+    int wx = (f2i_small(floorf(rox)) - lox) ^ smx;
+    int wy = (f2i_small(floorf(roy)) - loy) ^ smy;
+    int wz = (f2i_small(floorf(roz)) - loz) ^ smz;
+    unsigned steps = 0, iters = 0;
+    int      k = 0;
+    bool     hit = false;
+    int      cur_cell = -1, d = 0;
+    unsigned info = 0;
+    uint64_t cur_mask = 0;
+    int qx = 0, qy = 0, qz = 0;
+    auto locate = [&]() {
+        qx = (wx ^ smx) + offx; qy = (wy ^ smy) + offy; qz = (wz ^ smz) + offz;
+        if (POW2) {
+            qx &= P.n_pow2_mask; qy &= P.n_pow2_mask; qz &= P.n_pow2_mask;
+        } else {
+            qx -= qx >= n ? n : 0; qy -= qy >= n ? n : 0; qz -= qz >= n ? n : 0;
+        }
+        const int cell = ((qz >> 2) * nc + (qy >> 2)) * nc + (qx >> 2);
+        if (cell != cur_cell) {
+            const uint4 r = P.cells[cell];
+            cur_cell = cell;
+            info     = r.x;
+            cur_mask = (uint64_t)r.x | ((uint64_t)r.y << 32);
+            d        = (int)(((dhigh ? r.w : r.z) >> dshift) & 0xffu);
+        }
+    };
+    auto bit_of = [&]() { return (((wz ^ smz) & 3) << 4) | (((wy ^ smy) & 3) << 2) | ((wx ^ smx) & 3); };
+
+    bool live = (unsigned)(wx - wlox) <= span && (unsigned)(wy - wloy) <= span && (unsigned)(wz - wloz) <= span;
+    if (live) locate();  // the start voxel's cell (the voxel itself is never tested)
+    constexpr int walk = 4;
+    unsigned work = 0;  // loop trips of this lane, for the dispatch order of later launches
+    // at the top of the loop the current voxel has been tested (or is the start voxel) and the ray
+    // is inside the loaded area
+    while (live) {
+        work += 1u;
+#ifdef VRT_DIAG_ITERS
+        iters += 1u;
+#endif
+        if (d != 0) {
+            // ---- phase A: cross the empty box that starts at this cell
+            int fwx, fwy, fwz;  // last anchor of the box on each axis
+            const int lvl = (int)(info & 0xffu);
+            if (lvl > 0 && (1 << lvl) > d) {
+                const int m4 = (4 << lvl) - 1;
+                fwx = m4 >= n - 1 ? whix : min(wx + ((qx ^ ~smx) & m4), whix);
+                fwz = m4 >= n - 1 ? whiz : min(wz + ((qz ^ ~smz) & m4), whiz);
+                fwy = py ? whiy : min(~(int)((info >> 8) << 2), whiy);
+            } else {
+                const int r4 = (d - 1) << 2;
+                fwx = min((wx | 3) + r4, whix);
+                fwy = min((wy | 3) + r4, whiy);
+                fwz = min((wz | 3) + r4, whiz);
+            }
+            const float tx = ((float)(fwx + lnx + 1) - rnx) * inx;
+            const float ty = ((float)(fwy + lny + 1) - rny) * iny;
+            const float tz = ((float)(fwz + lnz + 1) - rnz) * inz;
+            k = argmin3(tx, ty, tz);
+            const float tk = k == 0 ? tx : (k == 1 ? ty : tz);
+            const float rtx = dnx * tk, rty = dny * tk, rtz = dnz * tk;
+            const float psx = rnx + rtx, psy = rny + rty, psz = rnz + rtz;
+            const float i0x = rintf(psx), i0y = rintf(psy), i0z = rintf(psz);
+            int vx = f2i_small(floorf(psx)) - lnx, vy = f2i_small(floorf(psy)) - lny, vz = f2i_small(floorf(psz)) - lnz;
+            const bool nearx = fabsf(psx - i0x) <= 0x1.0p-20f * ((rtx + fabsf(psx)) + 1.0f);
+            const bool neary = fabsf(psy - i0y) <= 0x1.0p-20f * ((rty + fabsf(psy)) + 1.0f);
+            const bool nearz = fabsf(psz - i0z) <= 0x1.0p-20f * ((rtz + fabsf(psz)) + 1.0f);
+            if (__any((nearx || neary || nearz) ? 1 : 0)) {
+                const float ttx = (i0x - rnx) * inx, tty = (i0y - rny) * iny, ttz = (i0z - rnz) * inz;
+                const bool  cx = ttx <= tk;
+                const bool  cy = k == 2 ? tty <= tk : tty < tk;
+                const bool  cz = ttz < tk;
+                vx = nearx ? f2i_small(i0x) - lnx - (cx ? 0 : 1) : vx;
+                vy = neary ? f2i_small(i0y) - lny - (cy ? 0 : 1) : vy;
+                vz = nearz ? f2i_small(i0z) - lnz - (cz ? 0 : 1) : vz;
+            }
+            vx = k == 0 ? fwx + 1 : min(max(vx, wx), fwx);
+            vy = k == 1 ? fwy + 1 : min(max(vy, wy), fwy);
+            vz = k == 2 ? fwz + 1 : min(max(vz, wz), fwz);
+            steps += (unsigned)((vx - wx) + (vy - wy) + (vz - wz));
+            wx = vx; wy = vy; wz = vz;
+            const int wk = k == 0 ? wx : (k == 1 ? wy : wz);
+            const int hk = k == 0 ? whix : (k == 1 ? whiy : whiz);
+            // the voxel just entered is tested even when it lies outside the loaded area; the ray
+            // ends after that test (raytrace.glsl:52 comes before the next :43)
+            locate();  // a box ends at a cell boundary on its exit axis
+            if (d == 0 && ((cur_mask >> bit_of()) & 1ull)) { hit = true; live = false; }
+            else if (wk > hk) live = false;
+        }
+        if (live && d == 0) {
+            // ---- phase B: a few unit steps through the non-empty cell(s)
+            int bit = bit_of();
+            for (int i = 0; i < walk; ++i) {
+#ifdef VRT_DIAG_ITERS
+                iters += 0x10000u;
+#endif
+                const float tx = ((float)(wx + lnx + 1) - rnx) * inx;
+                const float ty = ((float)(wy + lny + 1) - rny) * iny;
+                const float tz = ((float)(wz + lnz + 1) - rnz) * inz;
+                k = argmin3(tx, ty, tz);
+                wx += k == 0 ? 1 : 0; wy += k == 1 ? 1 : 0; wz += k == 2 ? 1 : 0;
+                steps += 1;
+                const int wk = k == 0 ? wx : (k == 1 ? wy : wz);
+                const int hk = k == 0 ? whix : (k == 1 ? whiy : whiz);
+                if ((wk & 3) == 0) {
+                    locate();
+                    bit = bit_of();
+                } else {
+                    bit += k == 0 ? dbx : (k == 1 ? dby : dbz);
+                }
+                if (d == 0 && ((cur_mask >> bit) & 1ull)) { hit = true; live = false; break; }
+                if (wk > hk) { live = false; break; }
+                if (d != 0) break;  // an empty cell: back to phase A
+            }
+        }
+    }
+    H.hit = hit ? 1 : 0; H.capped = 0; H.block_id = 0; H.k = 0; H.sk = 0;
+    if (hit) {
+        H.k = k; H.sk = k == 0 ? (px ? 1 : -1) : (k == 1 ? (py ? 1 : -1) : (pz ? 1 : -1));
+        // t as the reference computes it, in the unmirrored frame (see traverse_skip)
+        const int   pk = k == 0 ? (wx ^ smx) + lox + (px ? 0 : 1)
+                       : (k == 1 ? (wy ^ smy) + loy + (py ? 0 : 1) : (wz ^ smz) + loz + (pz ? 0 : 1));
+        const float th = ((float)pk - (k == 0 ? rox : (k == 1 ? roy : roz))) * (k == 0 ? invx : (k == 1 ? invy : invz));
+        H.t = th;
+        H.hx = rox + rdx * th; H.hy = roy + rdy * th; H.hz = roz + rdz * th;
+        locate();
+        H.block_id = (unsigned)((const T *)P.block)[((size_t)qz * (size_t)n + (size_t)qy) * (size_t)n + (size_t)qx];
+    } else {
+        H.t = -1.0f; H.hx = H.hy = H.hz = 0.0f;
+    }
+    H.vx = (wx ^ smx) + lox; H.vy = (wy ^ smy) + loy; H.vz = (wz ^ smz) + loz;
+    H.steps = steps; H.iters = iters; H.work = work;
+}
+
+// picks the traversal for this launch (wave uniform)
+template <typename T>
+VRT_DEV void traverse_auto(const TraceParams &P, float rox, float roy, float roz, float rdx, float rdy,
+                           float rdz, int lox, int loy, int loz, int upx, int upy, int upz, RayHit &H)
+{
+    if (P.need_cap) traverse_skip<T>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
+    else if (P.n_pow2_mask >= 0) traverse_cells<T, true>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
+    else traverse_cells<T, false>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
 }
 
 // ---------------------------------------------------------------------------
 // per-pixel prologue / epilogue shared by both kernels
 // ---------------------------------------------------------------------------
 // Wave tile = (64 >> tile_log2h) x (1 << tile_log2h) pixels; a workgroup stacks its four waves
-// vertically.  tile_log2h = 3 gives 8x8-pixel waves in a 8x32 block.
-VRT_DEV bool pixel_of_thread(const TraceParams &P, unsigned &col, unsigned &q, unsigned &row)
+// vertically.  tile_log2h = 3 gives 8x8-pixel waves in a 8x32 block.  `by` is the workgroup row.
+VRT_DEV bool pixel_of_thread(const TraceParams &P, unsigned by, unsigned &col, unsigned &q, unsigned &row)
 {
     const unsigned tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const unsigned lh = P.tile_log2h, tw = 64u >> lh;
     col = blockIdx.x * tw + (lane & (tw - 1));
-    q   = ((blockIdx.y * 4 + wave) << lh) + (lane >> (6 - lh));
+    q   = ((by * 4 + wave) << lh) + (lane >> (6 - lh));
     if (col >= P.w || q >= P.rows.rows) return false;
     if (P.rows.strip_h == 0) {
         row = P.rows.y0 + q;
@@ -323,6 +512,115 @@ VRT_DEV bool pixel_of_thread(const TraceParams &P, unsigned &col, unsigned &q, u
         row = ((q / P.rows.strip_h) * P.rows.parts + P.rows.part) * P.rows.strip_h + q % P.rows.strip_h;
     }
     return true;
+}
+
+// ---------------------------------------------------------------------------
+// dispatch order of workgroup rows
+// ---------------------------------------------------------------------------
+// The hardware starts workgroups in blockIdx order, and once every SIMD is full a frame takes as
+// long as its last wavefront.  Wavefronts differ by a factor of thirty (sky rows end after two or
+// three boxes, rows under the horizon skim the terrain for a hundred steps), so the frame is
+// shortest when the long rows start first and cheap ones fill the end.  Which rows are long
+// depends on the scene and the camera, so it is measured: each wavefront stores how many trips of
+// the traversal loop it made; the following launch reduces these to the longest time per row; the launch
+// after that finds the topmost row that is not cheap; and the one after that starts there, runs
+// down to the bottom and finishes with the rows above, all of which are cheap.  (One step per
+// launch keeps every step a single round trip to memory for a single wavefront.)  Only the order of
+// execution changes; every pixel is computed exactly as before.  Plain stores to a slot per
+// wavefront: nothing is shared inside a launch, so no atomics, barriers or fences are needed,
+// and the reader is a later kernel.
+constexpr unsigned SCHED_MAX_ROWS = 256;
+
+// Workgroup row of this workgroup.
+VRT_DEV unsigned sched_row(const TraceParams &P)
+{
+    unsigned s = 0;
+    if (P.sched.fixed_start >= 0) {
+        s = (unsigned)P.sched.fixed_start % gridDim.y;
+    } else if (P.sched.use_order) {
+        const unsigned v = P.sched.start[P.sched.generation & 1u];
+        if ((v >> 16) == P.sched.generation && (v & 0xffffu) < gridDim.y) s = v & 0xffffu;
+    }
+    unsigned by = blockIdx.y + s;
+    if (by >= gridDim.y) by -= gridDim.y;
+    return by;
+}
+
+// Maximum over the 64 lanes (all active), as a scalar: rotations inside each row of 16 lanes on the
+// DPP path of the VALU, then one lane per row.
+VRT_DEV unsigned wave_max(unsigned v)
+{
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false));  // row_ror:8
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false));  // row_ror:4
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xf, 0xf, false));  // row_ror:2
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xf, 0xf, false));  // row_ror:1
+    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+    const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+    return max(max(a, b), max(c, d));
+}
+
+// Called by every lane of a wavefront at its end: one plain store to the wavefront's own slot.
+VRT_DEV void sched_end(const TraceParams &P, unsigned by, unsigned work)
+{
+    const unsigned trips = wave_max(work);  // a wavefront runs the loop as often as its longest lane
+    if ((threadIdx.x & 63u) != 0) return;
+    const unsigned slot = (by * gridDim.x + blockIdx.x) * (blockDim.x / 64u) + (threadIdx.x >> 6);
+    P.sched.cost[(P.sched.generation & 1u) * P.sched.capacity + slot] = (P.sched.generation << 20) | min(trips + 1u, 0xfffffu);
+}
+
+// One wavefront per workgroup row: the longest wavefront of this row in the previous launch.
+VRT_DEV void sched_reduce_row(const TraceParams &P, unsigned by)
+{
+    const unsigned lane = threadIdx.x & 63u, per_row = gridDim.x * (blockDim.x / 64u);
+    const unsigned src = P.sched.generation - 1u;
+    const uint32_t *slots = P.sched.cost + (size_t)(src & 1u) * P.sched.capacity + (size_t)by * per_row;
+    unsigned c = 0;
+    bool known = true;
+    for (unsigned x = lane; x < per_row; x += 64u) {
+        const unsigned v = slots[x];
+        if ((v >> 20) == src) c = max(c, v & 0xfffffu); else known = false;
+    }
+    for (int o = 32; o > 0; o >>= 1) c = max(c, (unsigned)__shfl_xor((int)c, o));
+    if (__any(known ? 0 : 1)) c = 0;  // a wavefront without a time: the row counts as unknown
+    if (lane == 0) P.sched.row_longest[(P.sched.generation & 1u) * SCHED_MAX_ROWS + by] = (P.sched.generation << 20) | c;
+}
+
+// One wavefront per launch: from the row times the previous launch reduced, the start row of the next.
+VRT_DEV void sched_plan(const TraceParams &P)
+{
+    const unsigned lane = threadIdx.x & 63u, GY = gridDim.y;
+    const unsigned src = P.sched.generation - 1u;
+    const uint32_t *rows = P.sched.row_longest + (src & 1u) * SCHED_MAX_ROWS;
+    unsigned mine[SCHED_MAX_ROWS / 64];  // lane l keeps rows l, l + 64, ...
+    unsigned longest = 0, cheapest = 0xffffffffu;
+    for (unsigned i = 0; i < SCHED_MAX_ROWS / 64; ++i) {
+        const unsigned r = lane + 64u * i;
+        mine[i] = 0;
+        if (r < GY) {
+            const unsigned v = rows[r];
+            mine[i] = (v >> 20) == src ? (v & 0xfffffu) : 0u;
+            longest = max(longest, mine[i]);
+            cheapest = min(cheapest, mine[i]);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        longest = max(longest, (unsigned)__shfl_xor((int)longest, o));
+        cheapest = min(cheapest, (unsigned)__shfl_xor((int)cheapest, o));
+    }
+    // "not cheap": more than twice the cheapest row and more than an eighth of the longest.  (The rows
+    // that start a launch run with cold caches and come out a few microseconds slower than they are.)
+    const unsigned threshold = max(2u * cheapest, longest / 8u);
+    unsigned first = GY;
+    for (unsigned i = 0; i < SCHED_MAX_ROWS / 64; ++i) {
+        const unsigned r = lane + 64u * i;
+        if (r < GY && mine[i] > threshold) first = min(first, r);
+    }
+    for (int o = 32; o > 0; o >>= 1) first = min(first, (unsigned)__shfl_xor((int)first, o));
+    if (cheapest == 0) first = 0;  // a row without a time: keep the plain order
+    if (lane == 0) {
+        const unsigned next = P.sched.generation + 1u;
+        P.sched.start[next & 1u] = (next << 16) | (first < GY ? first : 0u);
+    }
 }
 
 // raytrace.glsl:120-123
@@ -378,7 +676,7 @@ template <typename T, bool HAS_DIST>
 __global__ __launch_bounds__(256) void k_trace_literal(const TraceParams P)
 {
     unsigned col, q, row;
-    if (!pixel_of_thread(P, col, q, row)) return;
+    if (!pixel_of_thread(P, blockIdx.y, col, q, row)) return;
     const unsigned gx = col, gy = P.h - row;  // render.comp:13
     float rdx, rdy, rdz;
     raygen(P, gx, gy, rdx, rdy, rdz);
@@ -393,17 +691,39 @@ __global__ __launch_bounds__(256) void k_trace_literal(const TraceParams P)
 template <typename T>
 __global__ __launch_bounds__(256) void k_trace_skip(const TraceParams P)
 {
-    unsigned col, q, row;
-    if (!pixel_of_thread(P, col, q, row)) return;
-    const unsigned gx = col, gy = P.h - row;
-    float rdx, rdy, rdz;
-    raygen(P, gx, gy, rdx, rdy, rdz);
-    const float rox = P.m[12], roy = P.m[13], roz = P.m[14];
-    // loaded area (raytrace.glsl:19-24), evaluated once per frame on the host
-    const int lox = P.lo[0], loy = P.lo[1], loz = P.lo[2], upx = P.up[0], upy = P.up[1], upz = P.up[2];
-    RayHit H;
-    traverse_skip<T>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
-    finish_pixel(P, gx, gy, (size_t)q * P.w + col, H);
+    const unsigned by = sched_row(P);
+    unsigned col, q, row, work = 0;
+    if (pixel_of_thread(P, by, col, q, row)) {
+#ifdef VRT_DIAG_CLOCK
+        const long long d0 = wall_clock64();
+#endif
+        const unsigned gx = col, gy = P.h - row;
+        float rdx, rdy, rdz;
+        raygen(P, gx, gy, rdx, rdy, rdz);
+        const float rox = P.m[12], roy = P.m[13], roz = P.m[14];
+        // loaded area (raytrace.glsl:19-24), evaluated once per frame on the host
+        const int lox = P.lo[0], loy = P.lo[1], loz = P.lo[2], upx = P.up[0], upy = P.up[1], upz = P.up[2];
+        RayHit H;
+        traverse_auto<T>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
+        work = H.work;
+        finish_pixel(P, gx, gy, (size_t)q * P.w + col, H);
+#ifdef VRT_DIAG_CLOCK
+        // diagnostic build: start tick (100 MHz) in the face plane, duration in the steps plane
+        const long long d1 = wall_clock64();
+        if (P.face) P.face[(size_t)q * P.w + col] = (int)(d0 & 0x7fffffff);
+        if (P.steps) P.steps[(size_t)q * P.w + col] = (unsigned)(d1 - d0);
+        if (P.t) P.t[(size_t)q * P.w + col] = (float)H.iters;  // with -DVRT_DIAG_ITERS as well: the loop counts
+#endif
+    }
+    if (P.sched.cost) {
+        sched_end(P, by, work);
+        // the bookkeeping is done by the workgroups that start first, which are far from the end of the launch
+        const unsigned first = blockIdx.y * gridDim.x + blockIdx.x;
+        if (first < gridDim.y && threadIdx.x < 64) {
+            sched_reduce_row(P, first);
+            if (first == 0) sched_plan(P);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -446,36 +766,49 @@ VRT_DEV void secondary_dir(unsigned pixel_index, unsigned index, int face, float
 template <typename T>
 __global__ __launch_bounds__(256) void k_trace_secondary(const TraceParams P, uint8_t *shadow, uint8_t *ao, uint32_t *sec_steps)
 {
-    unsigned col, q, row;
-    if (!pixel_of_thread(P, col, q, row)) return;
-    const unsigned gx = col, gy = P.h - row;
-    float rdx, rdy, rdz;
-    raygen(P, gx, gy, rdx, rdy, rdz);
-    const float rox = P.m[12], roy = P.m[13], roz = P.m[14];
-    // loaded area (raytrace.glsl:19-24), evaluated once per frame on the host
-    const int lox = P.lo[0], loy = P.lo[1], loz = P.lo[2], upx = P.up[0], upy = P.up[1], upz = P.up[2];
-    RayHit H;
-    traverse_skip<T>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
-    unsigned sh = 0, occ = 0, st = 0;
-    if (H.hit) {
-        const float nk = (float)(-H.sk);
-        const float sox = H.hx + (H.k == 0 ? nk : 0.0f) * 1e-3f;
-        const float soy = H.hy + (H.k == 1 ? nk : 0.0f) * 1e-3f;
-        const float soz = H.hz + (H.k == 2 ? nk : 0.0f) * 1e-3f;
-        const int face = 2 * H.k + (H.sk < 0 ? 1 : 0);
-        for (unsigned s = 0; s < 5; ++s) {
-            float sdx, sdy, sdz;
-            secondary_dir(row * P.w + col, s, face, sdx, sdy, sdz);
-            RayHit S;
-            traverse_skip<T>(P, sox, soy, soz, sdx, sdy, sdz, lox, loy, loz, upx, upy, upz, S);
-            st += S.steps;
-            if (S.hit) { if (s == 0) sh = 1; else ++occ; }
+    const unsigned by = sched_row(P);
+    unsigned col, q, row, work = 0;
+    if (pixel_of_thread(P, by, col, q, row)) {
+        const unsigned gx = col, gy = P.h - row;
+        float rdx, rdy, rdz;
+        raygen(P, gx, gy, rdx, rdy, rdz);
+        const float rox = P.m[12], roy = P.m[13], roz = P.m[14];
+        // loaded area (raytrace.glsl:19-24), evaluated once per frame on the host
+        const int lox = P.lo[0], loy = P.lo[1], loz = P.lo[2], upx = P.up[0], upy = P.up[1], upz = P.up[2];
+        RayHit H;
+        traverse_auto<T>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
+        unsigned sh = 0, occ = 0, st = 0;
+        work = H.work;
+        if (H.hit) {
+            const float nk = (float)(-H.sk);
+            const float sox = H.hx + (H.k == 0 ? nk : 0.0f) * 1e-3f;
+            const float soy = H.hy + (H.k == 1 ? nk : 0.0f) * 1e-3f;
+            const float soz = H.hz + (H.k == 2 ? nk : 0.0f) * 1e-3f;
+            const int face = 2 * H.k + (H.sk < 0 ? 1 : 0);
+            for (unsigned s = 0; s < 5; ++s) {
+                float sdx, sdy, sdz;
+                secondary_dir(row * P.w + col, s, face, sdx, sdy, sdz);
+                RayHit S;
+                traverse_auto<T>(P, sox, soy, soz, sdx, sdy, sdz, lox, loy, loz, upx, upy, upz, S);
+                st += S.steps;
+                work += S.work;
+                if (S.hit) { if (s == 0) sh = 1; else ++occ; }
+            }
+        }
+        const size_t i = (size_t)q * P.w + col;
+        if (shadow) shadow[i] = (uint8_t)sh;
+        if (ao) ao[i] = (uint8_t)occ;
+        if (sec_steps) sec_steps[i] = st;
+    }
+    if (P.sched.cost) {
+        sched_end(P, by, work);
+        // the bookkeeping is done by the workgroups that start first, which are far from the end of the launch
+        const unsigned first = blockIdx.y * gridDim.x + blockIdx.x;
+        if (first < gridDim.y && threadIdx.x < 64) {
+            sched_reduce_row(P, first);
+            if (first == 0) sched_plan(P);
         }
     }
-    const size_t i = (size_t)q * P.w + col;
-    if (shadow) shadow[i] = (uint8_t)sh;
-    if (ao) ao[i] = (uint8_t)occ;
-    if (sec_steps) sec_steps[i] = st;
 }
 
 static dim3 trace_grid(const TraceParams &p)

@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--mode", choices=["auto", "skip", "literal"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--time-every", type=int, default=8,
+                    help="bracket one frame in this many with HIP events (the events themselves cost stream time)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo: rehearsal of the multi-rank path on hosts without one GPU per rank "
                          "(frames are gathered through host memory; not a measurement)")
@@ -159,6 +161,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    core.kernel_time_sampling(max(1, min(args.time_every, args.steps)))
     core.kernel_time_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -203,6 +206,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_s * 1e3,
+                         "timed_launches": int(launches),
                          "kernel_mrays_s": W * H / kern_s / 1e6, "mean_steps_per_ray": sum_steps / (W * H)},
         }
         if world == 1 and not args.no_cpu_baseline:

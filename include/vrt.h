@@ -142,6 +142,11 @@ int vrt_download_world(vrt_ctx *ctx, void *block_out, uint32_t memory);
  * last vrt_kernel_time_reset.  Waits for the stream. */
 int vrt_kernel_time(vrt_ctx *ctx, double *total_ms, uint64_t *launches);
 int vrt_kernel_time_reset(vrt_ctx *ctx);
+/* Time one trace launch in `every_n` (default 1: all of them).  The two events around a launch cost
+ * a few microseconds of stream time, which a caller that issues frames back to back may not want on
+ * every frame; `launches` of vrt_kernel_time then counts the timed launches only.  every_n = 0 turns
+ * the timing off. */
+int vrt_kernel_time_sampling(vrt_ctx *ctx, uint32_t every_n);
 /* Name of the kernel the last vrt_trace launched ("literal" or "skip"). */
 const char *vrt_last_kernel_name(vrt_ctx *ctx);
 

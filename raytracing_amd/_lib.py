@@ -64,6 +64,7 @@ SYMBOLS = {
     "vrt_download_world": (C.c_int, [_CTX, C.c_void_p, C.c_uint32]),
     "vrt_kernel_time": (C.c_int, [_CTX, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "vrt_kernel_time_reset": (C.c_int, [_CTX]),
+    "vrt_kernel_time_sampling": (C.c_int, [_CTX, C.c_uint32]),
     "vrt_last_kernel_name": (C.c_char_p, [_CTX]),
     "vrt_stream": (C.c_void_p, [_CTX]),
     "vrt_last_error": (C.c_char_p, []),

@@ -70,6 +70,8 @@ struct vrt_ctx {
     // kernel timing
     hipEvent_t  ev0[kEventRing], ev1[kEventRing];
     int         ev_pending   = 0;
+    uint32_t    time_every   = 1;        // one launch in time_every is bracketed by events; 0 = none
+    uint64_t    launch_seq   = 0;
     double      total_ms     = 0.0;
     uint64_t    launches     = 0;
     const char *last_kernel  = "none";
@@ -304,14 +306,14 @@ int do_trace(vrt_ctx *c, const float *cam, uint32_t w, uint32_t h, const vrt::Ro
     p.bgra8 = (uint8_t *)dev[0]; p.voxel = (int32_t *)dev[1]; p.face = (int32_t *)dev[2]; p.steps = (uint32_t *)dev[3];
     p.t = (float *)dev[4]; p.hit_point = (float *)dev[5]; p.rgba = (float *)dev[6];
 
-    if (c->ev_pending == kEventRing) { int rc = drain_events(c); if (rc != VRT_OK) return rc; }
+    const bool timed = c->time_every != 0 && c->launch_seq++ % c->time_every == 0;
+    if (timed && c->ev_pending == kEventRing) { int rc = drain_events(c); if (rc != VRT_OK) return rc; }
     const int e = c->ev_pending;
-    HIP_TRY(hipEventRecord(c->ev0[e], c->stream));
+    if (timed) HIP_TRY(hipEventRecord(c->ev0[e], c->stream));
     if (use_skip) { int rc = attach_row_sched(c, p, 1); if (rc != VRT_OK) return rc; }
     if (use_skip) { HIP_TRY(vrt::launch_trace_skip(p, c->voxel_bytes, c->stream)); c->last_kernel = "skip"; }
     else          { HIP_TRY(vrt::launch_trace_literal(p, c->voxel_bytes, c->stream)); c->last_kernel = "literal"; }
-    HIP_TRY(hipEventRecord(c->ev1[e], c->stream));
-    c->ev_pending = e + 1;
+    if (timed) { HIP_TRY(hipEventRecord(c->ev1[e], c->stream)); c->ev_pending = e + 1; }
 
     if (out->memory == VRT_MEM_HOST) {
         for (int i = 0; i < 7; ++i)
@@ -486,14 +488,14 @@ int vrt_trace_secondary(vrt_ctx *c, const float cam[16], uint32_t w, uint32_t h,
         { int rc = ensure_stage(c, total); if (rc != VRT_OK) return rc; }
         for (int i = 0; i < 3; ++i) dev[i] = planes[i].bytes ? (char *)c->d_stage + planes[i].off : nullptr;
     }
-    if (c->ev_pending == kEventRing) { int rc = drain_events(c); if (rc != VRT_OK) return rc; }
+    const bool timed = c->time_every != 0 && c->launch_seq++ % c->time_every == 0;
+    if (timed && c->ev_pending == kEventRing) { int rc = drain_events(c); if (rc != VRT_OK) return rc; }
     const int e = c->ev_pending;
-    HIP_TRY(hipEventRecord(c->ev0[e], c->stream));
+    if (timed) HIP_TRY(hipEventRecord(c->ev0[e], c->stream));
     { int rc = attach_row_sched(c, p, 2); if (rc != VRT_OK) return rc; }
     HIP_TRY(vrt::launch_trace_secondary(p, c->voxel_bytes, (uint8_t *)dev[0], (uint8_t *)dev[1], (uint32_t *)dev[2], c->stream));
     c->last_kernel = "secondary";
-    HIP_TRY(hipEventRecord(c->ev1[e], c->stream));
-    c->ev_pending = e + 1;
+    if (timed) { HIP_TRY(hipEventRecord(c->ev1[e], c->stream)); c->ev_pending = e + 1; }
     if (out->memory == VRT_MEM_HOST) {
         for (int i = 0; i < 3; ++i)
             if (planes[i].bytes) HIP_TRY(hipMemcpyAsync(planes[i].host, dev[i], planes[i].bytes, hipMemcpyDeviceToHost, c->stream));
@@ -559,6 +561,14 @@ int vrt_kernel_time_reset(vrt_ctx *c)
     c->total_ms = 0.0;
     c->launches = 0;
     return rc;
+}
+
+int vrt_kernel_time_sampling(vrt_ctx *c, uint32_t every_n)
+{
+    if (!c) return fail(VRT_E_INVALID_ARG, "null argument");
+    c->time_every = every_n;
+    c->launch_seq = 0;
+    return VRT_OK;
 }
 
 const char *vrt_last_kernel_name(vrt_ctx *c) { return c ? c->last_kernel : "none"; }

@@ -194,6 +194,10 @@ class GraphicsCore:
     def kernel_time_reset(self):
         L.check(L.lib().vrt_kernel_time_reset(self._ctx))
 
+    def kernel_time_sampling(self, every_n):
+        """Bracket one trace launch in `every_n` with HIP events (default 1; 0 = none)."""
+        L.check(L.lib().vrt_kernel_time_sampling(self._ctx, int(every_n)))
+
     def last_kernel_name(self):
         return L.lib().vrt_last_kernel_name(self._ctx).decode()
 

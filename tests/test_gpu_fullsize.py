@@ -127,3 +127,20 @@ def test_caves_and_overhangs_defeat_the_pyramid_but_not_parity():
             want = O.trace(world, cam, 200, 120)
             for k in PLANES:
                 assert same(got[k], want[k]), (k, pos)
+
+
+def test_bench_frame_repeated_with_dispatch_feedback():
+    # the bench workload, twelve launches in a row: every launch returns the frame of the first
+    # (the later ones run their workgroup rows in the measured order)
+    p = scenes.pose_headline()
+    cam = scenes.cam16(p)
+    with GraphicsCore(grid_n=1024, voxel_format=VOXEL_PACKED_U8, trace_mode=TRACE_SKIP) as g:
+        g.generate_window(scenes.window_min(p.get_position(), 1024))
+        first = g.trace(cam, 1920, 1080, outputs=("bgra8", "steps", "voxel", "face", "t"))
+        for i in range(11):
+            again = g.trace(cam, 1920, 1080, outputs=("bgra8", "steps", "voxel", "face", "t"))
+            for k in first:
+                a, b = first[k], again[k]
+                if a.dtype == np.float32:
+                    a, b = a.view(np.uint32), b.view(np.uint32)
+                assert np.array_equal(a, b), (i, k)

@@ -263,7 +263,6 @@ int prepare_trace(vrt_ctx *c, const float *cam, uint32_t w, uint32_t h, const vr
         p.off[k] = r < 0 ? r + n : r;
     }
     { const char *v = std::getenv("VRT_TILE_LOG2H"); if (v) p.tile_log2h = (uint32_t)std::atoi(v) % 7u; }  // A/B only
-    { const char *v = std::getenv("VRT_SKIP_VARIANT"); p.variant = v ? (uint32_t)std::atoi(v) : 0u; }  // A/B only
     p.block = c->d_block;
     p.dist = c->dist_nonzero ? c->d_dist : nullptr;
     p.cells = c->d_cells; p.nc = (int)c->n / 4;

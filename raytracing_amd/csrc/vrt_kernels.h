@@ -47,7 +47,6 @@ struct TraceParams {
     int32_t  n_pow2_mask;  // n-1 if n is a power of two, else -1
     uint32_t max_steps;
     uint32_t tile_log2h;   // wave tile is (64 >> tile_log2h) x (1 << tile_log2h) pixels, 0..6
-    uint32_t variant;      // selects an experimental kernel form in A/B measurements; 0 = default
     uint32_t need_cap;     // max_steps can end a regular ray (max_steps < 3n): test it in the skip loop
     RowSched sched;
     // world

@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
-"""A/B of skip-kernel forms in ONE process on the bench workload: interleaved rounds,
-HIP-event kernel time per launch (median and min per variant).
-usage: ab_variants.py [variants, default "1,2"] [rounds]"""
+"""A/B of skip-kernel settings in ONE process on the bench workload: interleaved rounds,
+HIP-event kernel time per launch (median and min per setting); every setting must return the
+frame of the first, bit for bit.  The setting is the value of the environment variable named by
+AB_VAR, which the library reads at every launch:
+  VRT_NO_ROW_ORDER  1 = workgroup rows top to bottom, 0 = measured dispatch order (default)
+  VRT_ROW_BLOCK0    fixed start row block (x = measured)
+  VRT_TILE_LOG2H    wave tile height 2^k rows
+usage: AB_VAR=VRT_NO_ROW_ORDER ab_variants.py 1,0 [rounds]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -19,7 +24,7 @@ frame = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
 ref = None
 times = {v: [] for v in variants}
 for v in variants:  # correctness of each variant against the first
-    os.environ[os.environ.get("AB_VAR", "VRT_SKIP_VARIANT")] = v
+    os.environ[os.environ.get("AB_VAR", "VRT_NO_ROW_ORDER")] = v
     out = g.trace(cam, W, H, outputs=("bgra8", "steps", "voxel", "face", "t"))
     if ref is None:
         ref = out
@@ -30,7 +35,7 @@ for v in variants:  # correctness of each variant against the first
             assert np.array_equal(a, b), f"variant {v} differs from {variants[0]} on {k}: {(a != b).sum()} elements"
 for r in range(rounds):
     for v in variants:
-        os.environ[os.environ.get("AB_VAR", "VRT_SKIP_VARIANT")] = v
+        os.environ[os.environ.get("AB_VAR", "VRT_NO_ROW_ORDER")] = v
         g.kernel_time_reset()
         for _ in range(20):
             g.trace_device(cam, W, H, 0, H, {"bgra8": frame.data_ptr()})

@@ -11,7 +11,7 @@ run_pass() {
   name=$1; shift
   ctrs=$1; shift
   timeout -s KILL 120 rocprofv3 --pmc $ctrs --output-format csv -d "$OUT/pmc_$name" -- \
-      python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > "$OUT/pmc_$name.log" 2>&1
+      python3 bench.py --warmup 1 --no-cpu-baseline "$@" > "$OUT/pmc_$name.log" 2>&1
   rc=$?
   echo "pass $name rc=$rc"
   return $rc

@@ -170,10 +170,11 @@ def main():
     dt = time.perf_counter() - t0
     kern_ms, launches = core.kernel_time()
 
+    kern_max_s = kern_ms / 1e3 / max(launches, 1)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if host else "cuda")
+        t = torch.tensor([dt, kern_max_s], dtype=torch.float64, device="cpu" if host else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, kern_max_s = float(t[0].item()), float(t[1].item())
 
     if rank == 0:
         rays = W * H * args.steps * world
@@ -194,6 +195,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            # the same job without the framebuffer gather: every rank's frame / the slowest rank's kernel
+            "value_without_gather": rays / args.steps / kern_max_s / 1e6,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

@@ -354,13 +354,18 @@ VRT_DEV void traverse_cells(const TraceParams &P, float rox, float roy, float ro
     int wx = (f2i_small(floorf(rox)) - lox) ^ smx;
     int wy = (f2i_small(floorf(roy)) - loy) ^ smy;
     int wz = (f2i_small(floorf(roz)) - loz) ^ smz;
-    unsigned steps = 0, iters = 0;
+    // every step moves one axis by +1 in the mirrored frame: the step count is the distance from here
+    const int w0 = wx + wy + wz;
+    unsigned iters = 0;
     int      k = 0;
     bool     hit = false;
-    int      cur_cell = -1, d = 0;
+    int      d = 0;
     unsigned info = 0;
     uint64_t cur_mask = 0;
-    int qx = 0, qy = 0, qz = 0;
+    int qx = 0, qy = 0, qz = 0;  // texel of the anchor at the last cell lookup
+    int bit = 0;                 // mask bit of the current voxel while it stands in a non-empty cell
+    // Looks up the cell of the current anchor.  Every caller has just entered a new cell (or is the
+    // start), so the record is always loaded.
     auto locate = [&]() {
         qx = (wx ^ smx) + offx; qy = (wy ^ smy) + offy; qz = (wz ^ smz) + offz;
         if (POW2) {
@@ -368,16 +373,17 @@ VRT_DEV void traverse_cells(const TraceParams &P, float rox, float roy, float ro
         } else {
             qx -= qx >= n ? n : 0; qy -= qy >= n ? n : 0; qz -= qz >= n ? n : 0;
         }
-        const int cell = ((qz >> 2) * nc + (qy >> 2)) * nc + (qx >> 2);
-        if (cell != cur_cell) {
-            const uint4 r = P.cells[cell];
-            cur_cell = cell;
-            info     = r.x;
-            cur_mask = (uint64_t)r.x | ((uint64_t)r.y << 32);
-            d        = (int)(((dhigh ? r.w : r.z) >> dshift) & 0xffu);
-        }
+        const unsigned cell = (unsigned)(((qz >> 2) * nc + (qy >> 2)) * nc + (qx >> 2));
+        const uint4 r = P.cells[cell];
+        info     = r.x;
+        cur_mask = (uint64_t)r.x | ((uint64_t)r.y << 32);
+        d        = (int)(((dhigh ? r.w : r.z) >> dshift) & 0xffu);
+        bit      = ((qz & 3) << 4) | ((qy & 3) << 2) | (qx & 3);  // off is a multiple of 4
     };
-    auto bit_of = [&]() { return (((wz ^ smz) & 3) << 4) | (((wy ^ smy) & 3) << 2) | ((wx ^ smx) & 3); };
+    // margin of the exit-point test below, as 0.5 - 2^-20 * (|pos| + |origin| + 1) = thr0 - 2^-20 * |pos|
+    const float thr0x = 0.5f - 0x1.0p-20f * (fabsf(rnx) + 1.0f);
+    const float thr0y = 0.5f - 0x1.0p-20f * (fabsf(rny) + 1.0f);
+    const float thr0z = 0.5f - 0x1.0p-20f * (fabsf(rnz) + 1.0f);
 
     bool live = (unsigned)(wx - wlox) <= span && (unsigned)(wy - wloy) <= span && (unsigned)(wz - wloz) <= span;
     if (live) locate();  // the start voxel's cell (the voxel itself is never tested)
@@ -410,14 +416,17 @@ VRT_DEV void traverse_cells(const TraceParams &P, float rox, float roy, float ro
             const float tz = ((float)(fwz + lnz + 1) - rnz) * inz;
             k = argmin3(tx, ty, tz);
             const float tk = k == 0 ? tx : (k == 1 ? ty : tz);
-            const float rtx = dnx * tk, rty = dny * tk, rtz = dnz * tk;
-            const float psx = rnx + rtx, psy = rny + rty, psz = rnz + rtz;
-            const float i0x = rintf(psx), i0y = rintf(psy), i0z = rintf(psz);
-            int vx = f2i_small(floorf(psx)) - lnx, vy = f2i_small(floorf(psy)) - lny, vz = f2i_small(floorf(psz)) - lnz;
-            const bool nearx = fabsf(psx - i0x) <= 0x1.0p-20f * ((rtx + fabsf(psx)) + 1.0f);
-            const bool neary = fabsf(psy - i0y) <= 0x1.0p-20f * ((rty + fabsf(psy)) + 1.0f);
-            const bool nearz = fabsf(psz - i0z) <= 0x1.0p-20f * ((rtz + fabsf(psz)) + 1.0f);
+            // anchors at the exit from the exit point, where it is clear of every plane.  The point is
+            // off by at most 2^-24 * (3|i - ro| + |rd t| + |pos|) < 2^-21 * (|pos| + |ro| + 1); a plane
+            // within twice that is settled by comparing plane parameters instead (see traverse_skip).
+            const float psx = rnx + dnx * tk, psy = rny + dny * tk, psz = rnz + dnz * tk;
+            const float flx = floorf(psx), fly = floorf(psy), flz = floorf(psz);
+            int vx = f2i_small(flx) - lnx, vy = f2i_small(fly) - lny, vz = f2i_small(flz) - lnz;
+            const bool nearx = fabsf((psx - flx) - 0.5f) >= __builtin_fmaf(fabsf(psx), -0x1.0p-20f, thr0x);
+            const bool neary = fabsf((psy - fly) - 0.5f) >= __builtin_fmaf(fabsf(psy), -0x1.0p-20f, thr0y);
+            const bool nearz = fabsf((psz - flz) - 0.5f) >= __builtin_fmaf(fabsf(psz), -0x1.0p-20f, thr0z);
             if (__any((nearx || neary || nearz) ? 1 : 0)) {
+                const float i0x = rintf(psx), i0y = rintf(psy), i0z = rintf(psz);
                 const float ttx = (i0x - rnx) * inx, tty = (i0y - rny) * iny, ttz = (i0z - rnz) * inz;
                 const bool  cx = ttx <= tk;
                 const bool  cy = k == 2 ? tty <= tk : tty < tk;
@@ -426,22 +435,19 @@ VRT_DEV void traverse_cells(const TraceParams &P, float rox, float roy, float ro
                 vy = neary ? f2i_small(i0y) - lny - (cy ? 0 : 1) : vy;
                 vz = nearz ? f2i_small(i0z) - lnz - (cz ? 0 : 1) : vz;
             }
-            vx = k == 0 ? fwx + 1 : min(max(vx, wx), fwx);
-            vy = k == 1 ? fwy + 1 : min(max(vy, wy), fwy);
-            vz = k == 2 ? fwz + 1 : min(max(vz, wz), fwz);
-            steps += (unsigned)((vx - wx) + (vy - wy) + (vz - wz));
-            wx = vx; wy = vy; wz = vz;
+            wx = k == 0 ? fwx + 1 : min(max(vx, wx), fwx);
+            wy = k == 1 ? fwy + 1 : min(max(vy, wy), fwy);
+            wz = k == 2 ? fwz + 1 : min(max(vz, wz), fwz);
             const int wk = k == 0 ? wx : (k == 1 ? wy : wz);
             const int hk = k == 0 ? whix : (k == 1 ? whiy : whiz);
             // the voxel just entered is tested even when it lies outside the loaded area; the ray
             // ends after that test (raytrace.glsl:52 comes before the next :43)
             locate();  // a box ends at a cell boundary on its exit axis
-            if (d == 0 && ((cur_mask >> bit_of()) & 1ull)) { hit = true; live = false; }
+            if (d == 0 && ((cur_mask >> bit) & 1ull)) { hit = true; live = false; }
             else if (wk > hk) live = false;
         }
         if (live && d == 0) {
             // ---- phase B: a few unit steps through the non-empty cell(s)
-            int bit = bit_of();
             for (int i = 0; i < walk; ++i) {
 #ifdef VRT_DIAG_ITERS
                 iters += 0x10000u;
@@ -451,15 +457,10 @@ VRT_DEV void traverse_cells(const TraceParams &P, float rox, float roy, float ro
                 const float tz = ((float)(wz + lnz + 1) - rnz) * inz;
                 k = argmin3(tx, ty, tz);
                 wx += k == 0 ? 1 : 0; wy += k == 1 ? 1 : 0; wz += k == 2 ? 1 : 0;
-                steps += 1;
                 const int wk = k == 0 ? wx : (k == 1 ? wy : wz);
                 const int hk = k == 0 ? whix : (k == 1 ? whiy : whiz);
-                if ((wk & 3) == 0) {
-                    locate();
-                    bit = bit_of();
-                } else {
-                    bit += k == 0 ? dbx : (k == 1 ? dby : dbz);
-                }
+                if ((wk & 3) == 0) locate();
+                else bit += k == 0 ? dbx : (k == 1 ? dby : dbz);
                 if (d == 0 && ((cur_mask >> bit) & 1ull)) { hit = true; live = false; break; }
                 if (wk > hk) { live = false; break; }
                 if (d != 0) break;  // an empty cell: back to phase A
@@ -475,13 +476,12 @@ VRT_DEV void traverse_cells(const TraceParams &P, float rox, float roy, float ro
         const float th = ((float)pk - (k == 0 ? rox : (k == 1 ? roy : roz))) * (k == 0 ? invx : (k == 1 ? invy : invz));
         H.t = th;
         H.hx = rox + rdx * th; H.hy = roy + rdy * th; H.hz = roz + rdz * th;
-        locate();
-        H.block_id = (unsigned)((const T *)P.block)[((size_t)qz * (size_t)n + (size_t)qy) * (size_t)n + (size_t)qx];
+        H.block_id = load_block<T>(P, (wx ^ smx) + lox, (wy ^ smy) + loy, (wz ^ smz) + loz);
     } else {
         H.t = -1.0f; H.hx = H.hy = H.hz = 0.0f;
     }
     H.vx = (wx ^ smx) + lox; H.vy = (wy ^ smy) + loy; H.vz = (wz ^ smz) + loz;
-    H.steps = steps; H.iters = iters; H.work = work;
+    H.steps = (unsigned)(wx + wy + wz - w0); H.iters = iters; H.work = work;
 }
 
 // picks the traversal for this launch (wave uniform)

@@ -67,6 +67,21 @@ def cpu_baseline(core, cam, steps_plane):
             "matches_gpu_steps": bool(ok)}
 
 
+class stdout_to_stderr:
+    """RCCL prints a version banner on stdout when its communicator comes up; this run's stdout is
+    reserved for the one JSON line, so the file descriptor is pointed at stderr meanwhile."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -74,6 +89,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--mode", choices=["auto", "skip", "literal"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="run the RCCL gather path with a single rank as well (rehearsal of the N > 1 code on one GPU)")
     ap.add_argument("--time-every", type=int, default=8,
                     help="bracket one frame in this many with HIP events (the events themselves cost stream time)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -90,11 +107,20 @@ def main():
     if args.backend == "gloo":
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("gloo")
+    multi = world > 1 or args.force_gather  # frames are gathered to rank 0
+    if multi:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+        with stdout_to_stderr():
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                dist.barrier()  # brings the communicator up now rather than inside the timed region
+                torch.cuda.synchronize()
+            else:
+                dist.init_process_group("gloo")
 
     mode = {"auto": TRACE_AUTO, "skip": TRACE_SKIP, "literal": TRACE_LITERAL}[args.mode]
     core = GraphicsCore(width=W, height=H, device=local_rank, grid_n=N_GRID, voxel_format=VOXEL_PACKED_U8,
@@ -114,7 +140,7 @@ def main():
     frames = [torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
     steps_t = torch.zeros((H, W), dtype=torch.int32, device="cuda")
     gathered = [None, None]
-    if world > 1 and rank == 0:
+    if multi and rank == 0:
         gathered = [[torch.zeros((H, W, 4), dtype=torch.uint8, device="cpu" if host else "cuda") for _ in range(world)]
                     for _ in range(2)]
     pending = [None, None]
@@ -132,14 +158,14 @@ def main():
     def step():
         b = counter[0] & 1
         counter[0] += 1
-        if world > 1 and not host:
+        if multi and not host:
             with torch.cuda.stream(stream):
                 if pending[b] is not None:
                     pending[b].wait()                # the trace below may overwrite frames[b] only after its gather
                 core.trace_device(cam, W, H, 0, H, {"bgra8": frames[b].data_ptr()})
                 # RCCL gather to rank 0, ordered behind the trace on the context's stream
                 pending[b] = dist.gather(frames[b], gathered[b], dst=0, async_op=True)
-        elif world > 1:
+        elif multi:
             core.trace_device(cam, W, H, 0, H, {"bgra8": frames[b].data_ptr()})
             core.sync()
             dist.gather(frames[b].cpu(), gathered[b], dst=0)
@@ -154,7 +180,7 @@ def main():
                 pending[b] = None
         core.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -171,7 +197,7 @@ def main():
     kern_ms, launches = core.kernel_time()
 
     kern_max_s = kern_ms / 1e3 / max(launches, 1)
-    if world > 1:
+    if multi:
         t = torch.tensor([dt, kern_max_s], dtype=torch.float64, device="cpu" if host else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, kern_max_s = float(t[0].item()), float(t[1].item())
@@ -216,8 +242,11 @@ def main():
             line["cpu_baseline"] = cpu_baseline(core, cam, steps_np)
         print(json.dumps(line), flush=True)
 
+    if multi and rank == 0 and not host:
+        # the last gathered frame of rank 0 is its own last frame
+        assert torch.equal(gathered[(counter[0] - 1) & 1][0], frames[(counter[0] - 1) & 1]), "gather returned another frame"
     core.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

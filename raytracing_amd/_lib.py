@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_DIR, "libvrt.so")
+LIB_PATH = os.environ.get("VRT_LIB", os.path.join(_DIR, "libvrt.so"))  # VRT_LIB: another build of the library, for A/B runs
 
 VRT_OK = 0
 VRT_E_INVALID_ARG = -1

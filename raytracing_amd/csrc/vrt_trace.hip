@@ -1,14 +1,20 @@
 // vrt_trace.hip -- primary-ray kernels for gfx950.
 //
-// One thread per pixel; a wavefront covers a small rectangle of pixels (8x8 by default), so
-// its 64 rays stay spatially coherent; a 256-thread workgroup stacks four such tiles.
+// One thread per pixel; a wavefront covers a 16x4-pixel tile, so its 64 rays stay spatially
+// coherent; a 256-thread workgroup stacks four such tiles.
 //
-//   k_trace_literal : one voxel per iteration, straight restatement of
-//                     raytrace.glsl:26-77 (reads the linear block / distance images).
-//   k_trace_skip    : the same visit order reproduced exactly, but empty space is
-//                     crossed in one iteration per empty box.  Reads one 16-byte record
-//                     per 4^3 cell visited (occupancy mask + octant distances) instead
-//                     of one voxel per step; the voxel image is read once, at the hit.
+//   k_trace_literal   : one voxel per iteration, straight restatement of
+//                       raytrace.glsl:26-77 (reads the linear block / distance images).
+//   k_trace_skip      : the same visit order reproduced exactly, but empty space is crossed
+//                       in one step per empty box (traverse_cells: two-phase loop; traverse_skip:
+//                       one step per trip, kept for callers that set a small step cap).  Reads one
+//                       16-byte record per 4^3 cell visited (occupancy mask + octant distances)
+//                       instead of one voxel per step; the voxel image is read once, at the hit.
+//   k_trace_secondary : the primary ray and, per hit, a shadow ray and four ambient-occlusion
+//                       rays through the same traversal (no reference counterpart).
+//
+// The skip kernels also choose the order in which their workgroup rows are dispatched from
+// what earlier launches measured (see "dispatch order of workgroup rows" below).
 //
 // Reference lines followed: render.comp:6-14 (entry, crosshair, flipped store),
 // raytrace.glsl:19-24 (loaded area), :26-77 (traversal), :117-134 (ray generation,

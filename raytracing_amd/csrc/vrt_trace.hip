@@ -328,52 +328,26 @@ VRT_DEV void traverse_skip(const TraceParams &P, float rox, float roy, float roz
 // Every step moves towards + in the mirrored frame, so only the stepped axis can leave the
 // window and only its upper bound needs a test; the voxel just entered is tested for a hit
 // before that, as the reference does (raytrace.glsl:52 comes before the next :43).
+// The ray as a resumable object: begin() sets it up, trip() runs one trip of the loop for the lanes
+// whose ray is live, finish() turns the end state into the reference's outputs.  traverse_cells
+// below runs one ray per lane to the end; the stream kernel keeps lanes busy by starting a new ray
+// in a lane whose ray has ended.
 template <typename T, bool POW2>
-VRT_DEV void traverse_cells(const TraceParams &P, float rox, float roy, float roz, float rdx, float rdy,
-                            float rdz, int lox, int loy, int loz, int upx, int upy, int upz, RayHit &H)
-{
-    const float invx = 1.0f / rdx, invy = 1.0f / rdy, invz = 1.0f / rdz;
-    const float big = 0x1.0p100f;
-    const bool regular = (rdx != 0.0f) && (rdy != 0.0f) && (rdz != 0.0f) && (fabsf(invx) < big) &&
-                         (fabsf(invy) < big) && (fabsf(invz) < big);
-    if (!regular) {
-        traverse_literal<T, false>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
-        return;
-    }
-    const int n = P.n, nc = P.nc;
-    const bool px = rdx > 0.0f, py = rdy > 0.0f, pz = rdz > 0.0f;
-    const int  smx = px ? 0 : -1, smy = py ? 0 : -1, smz = pz ? 0 : -1;
-    const float rnx = px ? rox : -rox, rny = py ? roy : -roy, rnz = pz ? roz : -roz;
-    const float dnx = fabsf(rdx), dny = fabsf(rdy), dnz = fabsf(rdz);
-    const float inx = fabsf(invx), iny = fabsf(invy), inz = fabsf(invz);
-    const int  lnx = px ? lox : -lox, lny = py ? loy : -loy, lnz = pz ? loz : -loz;
-    const int  wlox = px ? 0 : 1 - n, wloy = py ? 0 : 1 - n, wloz = pz ? 0 : 1 - n;
-    const int  whix = wlox + (n - 3), whiy = wloy + (n - 3), whiz = wloz + (n - 3);
-    const unsigned span = (unsigned)(n - 3);
-    const int  offx = P.off[0], offy = P.off[1], offz = P.off[2];
-    const int  oct = (px ? 1 : 0) | (py ? 2 : 0) | (pz ? 4 : 0);
-    const int  dshift = 8 * (oct & 3);
-    const bool dhigh = oct >= 4;
-    // change of the mask bit index (z*16 + y*4 + x of the unmirrored voxel) per unit step
-    const int  dbx = px ? 1 : -1, dby = py ? 4 : -4, dbz = pz ? 16 : -16;
+struct CellRay {
+    // per ray constants (mirrored frame)
+    float rnx, rny, rnz, dnx, dny, dnz, inx, iny, inz, thr0x, thr0y, thr0z;
+    int   lnx, lny, lnz, smx, smy, smz;
+    int   dshift;  // bit 5: the octant byte lives in the record's .w word
+    // state
+    int      wx, wy, wz, w0, k, d, bit, qx, qy, qz;
+    unsigned info, work, iters;
+    uint64_t cur_mask;
+    bool     live, hit;
 
-    int wx = (f2i_small(floorf(rox)) - lox) ^ smx;
-    int wy = (f2i_small(floorf(roy)) - loy) ^ smy;
-    int wz = (f2i_small(floorf(roz)) - loz) ^ smz;
-    // every step moves one axis by +1 in the mirrored frame: the step count is the distance from here
-    const int w0 = wx + wy + wz;
-    unsigned iters = 0;
-    int      k = 0;
-    bool     hit = false;
-    int      d = 0;
-    unsigned info = 0;
-    uint64_t cur_mask = 0;
-    int qx = 0, qy = 0, qz = 0;  // texel of the anchor at the last cell lookup
-    int bit = 0;                 // mask bit of the current voxel while it stands in a non-empty cell
-    // Looks up the cell of the current anchor.  Every caller has just entered a new cell (or is the
-    // start), so the record is always loaded.
-    auto locate = [&]() {
-        qx = (wx ^ smx) + offx; qy = (wy ^ smy) + offy; qz = (wz ^ smz) + offz;
+    VRT_DEV void locate(const TraceParams &P)
+    {
+        const int n = P.n, nc = P.nc;
+        qx = (wx ^ smx) + P.off[0]; qy = (wy ^ smy) + P.off[1]; qz = (wz ^ smz) + P.off[2];
         if (POW2) {
             qx &= P.n_pow2_mask; qy &= P.n_pow2_mask; qz &= P.n_pow2_mask;
         } else {
@@ -383,21 +357,53 @@ VRT_DEV void traverse_cells(const TraceParams &P, float rox, float roy, float ro
         const uint4 r = P.cells[cell];
         info     = r.x;
         cur_mask = (uint64_t)r.x | ((uint64_t)r.y << 32);
-        d        = (int)(((dhigh ? r.w : r.z) >> dshift) & 0xffu);
+        d        = (int)((((dshift & 32) ? r.w : r.z) >> (dshift & 31)) & 0xffu);
         bit      = ((qz & 3) << 4) | ((qy & 3) << 2) | (qx & 3);  // off is a multiple of 4
-    };
-    // margin of the exit-point test below, as 0.5 - 2^-20 * (|pos| + |origin| + 1) = thr0 - 2^-20 * |pos|
-    const float thr0x = 0.5f - 0x1.0p-20f * (fabsf(rnx) + 1.0f);
-    const float thr0y = 0.5f - 0x1.0p-20f * (fabsf(rny) + 1.0f);
-    const float thr0z = 0.5f - 0x1.0p-20f * (fabsf(rnz) + 1.0f);
+    }
 
-    bool live = (unsigned)(wx - wlox) <= span && (unsigned)(wy - wloy) <= span && (unsigned)(wz - wloz) <= span;
-    if (live) locate();  // the start voxel's cell (the voxel itself is never tested)
-    constexpr int walk = 4;
-    unsigned work = 0;  // loop trips of this lane, for the dispatch order of later launches
-    // at the top of the loop the current voxel has been tested (or is the start voxel) and the ray
-    // is inside the loaded area
-    while (live) {
+    // false: the direction has a zero or non-finite component and the ray takes the literal loop
+    VRT_DEV bool begin(const TraceParams &P, float rox, float roy, float roz, float rdx, float rdy, float rdz,
+                       int lox, int loy, int loz)
+    {
+        const float invx = 1.0f / rdx, invy = 1.0f / rdy, invz = 1.0f / rdz;
+        const float big = 0x1.0p100f;
+        const bool regular = (rdx != 0.0f) && (rdy != 0.0f) && (rdz != 0.0f) && (fabsf(invx) < big) &&
+                             (fabsf(invy) < big) && (fabsf(invz) < big);
+        live = false; hit = false; k = 0; d = 0; info = 0; cur_mask = 0; work = 0; iters = 0; bit = 0;
+        qx = qy = qz = 0;
+        if (!regular) return false;
+        const int n = P.n;
+        const bool px = rdx > 0.0f, py = rdy > 0.0f, pz = rdz > 0.0f;
+        smx = px ? 0 : -1; smy = py ? 0 : -1; smz = pz ? 0 : -1;
+        rnx = px ? rox : -rox; rny = py ? roy : -roy; rnz = pz ? roz : -roz;
+        dnx = fabsf(rdx); dny = fabsf(rdy); dnz = fabsf(rdz);
+        inx = fabsf(invx); iny = fabsf(invy); inz = fabsf(invz);
+        lnx = px ? lox : -lox; lny = py ? loy : -loy; lnz = pz ? loz : -loz;
+        const int oct = (px ? 1 : 0) | (py ? 2 : 0) | (pz ? 4 : 0);
+        dshift = 8 * (oct & 3) + (oct >= 4 ? 32 : 0);
+        // margin of the exit-point test, as 0.5 - 2^-20 * (|pos| + |origin| + 1) = thr0 - 2^-20 * |pos|
+        thr0x = 0.5f - 0x1.0p-20f * (fabsf(rnx) + 1.0f);
+        thr0y = 0.5f - 0x1.0p-20f * (fabsf(rny) + 1.0f);
+        thr0z = 0.5f - 0x1.0p-20f * (fabsf(rnz) + 1.0f);
+        wx = (f2i_small(floorf(rox)) - lox) ^ smx;
+        wy = (f2i_small(floorf(roy)) - loy) ^ smy;
+        wz = (f2i_small(floorf(roz)) - loz) ^ smz;
+        // every step moves one axis by +1 in the mirrored frame: the step count is the distance from here
+        w0 = wx + wy + wz;
+        const unsigned span = (unsigned)(n - 3);
+        // loop test lower < a + s01 < upper  <=>  wlo <= w <= wlo + n - 3, wlo = 0 (s > 0) or 1 - n (s < 0)
+        live = (unsigned)(wx - (smx & (1 - n))) <= span && (unsigned)(wy - (smy & (1 - n))) <= span &&
+               (unsigned)(wz - (smz & (1 - n))) <= span;
+        if (live) locate(P);  // the start voxel's cell (the voxel itself is never tested)
+        return true;
+    }
+
+    // One trip for the lanes with a live ray.  On entry the current voxel has been tested (or is the
+    // start voxel) and lies inside the loaded area.
+    VRT_DEV void trip(const TraceParams &P)
+    {
+        const int n = P.n;
+        const int whix = (smx & (1 - n)) + (n - 3), whiy = (smy & (1 - n)) + (n - 3), whiz = (smz & (1 - n)) + (n - 3);
         work += 1u;
 #ifdef VRT_DIAG_ITERS
         iters += 1u;
@@ -410,7 +416,7 @@ VRT_DEV void traverse_cells(const TraceParams &P, float rox, float roy, float ro
                 const int m4 = (4 << lvl) - 1;
                 fwx = m4 >= n - 1 ? whix : min(wx + ((qx ^ ~smx) & m4), whix);
                 fwz = m4 >= n - 1 ? whiz : min(wz + ((qz ^ ~smz) & m4), whiz);
-                fwy = py ? whiy : min(~(int)((info >> 8) << 2), whiy);
+                fwy = smy == 0 ? whiy : min(~(int)((info >> 8) << 2), whiy);
             } else {
                 const int r4 = (d - 1) << 2;
                 fwx = min((wx | 3) + r4, whix);
@@ -448,13 +454,15 @@ VRT_DEV void traverse_cells(const TraceParams &P, float rox, float roy, float ro
             const int hk = k == 0 ? whix : (k == 1 ? whiy : whiz);
             // the voxel just entered is tested even when it lies outside the loaded area; the ray
             // ends after that test (raytrace.glsl:52 comes before the next :43)
-            locate();  // a box ends at a cell boundary on its exit axis
+            locate(P);  // a box ends at a cell boundary on its exit axis
             if (d == 0 && ((cur_mask >> bit) & 1ull)) { hit = true; live = false; }
             else if (wk > hk) live = false;
         }
         if (live && d == 0) {
             // ---- phase B: a few unit steps through the non-empty cell(s)
-            for (int i = 0; i < walk; ++i) {
+            // change of the mask bit index (z*16 + y*4 + x of the unmirrored voxel) per unit step
+            const int dbx = 1 | smx, dby = 4 ^ (smy & ~7), dbz = 16 ^ (smz & ~31);  // +-1, +-4, +-16
+            for (int i = 0; i < 4; ++i) {
 #ifdef VRT_DIAG_ITERS
                 iters += 0x10000u;
 #endif
@@ -465,7 +473,7 @@ VRT_DEV void traverse_cells(const TraceParams &P, float rox, float roy, float ro
                 wx += k == 0 ? 1 : 0; wy += k == 1 ? 1 : 0; wz += k == 2 ? 1 : 0;
                 const int wk = k == 0 ? wx : (k == 1 ? wy : wz);
                 const int hk = k == 0 ? whix : (k == 1 ? whiy : whiz);
-                if ((wk & 3) == 0) locate();
+                if ((wk & 3) == 0) locate(P);
                 else bit += k == 0 ? dbx : (k == 1 ? dby : dbz);
                 if (d == 0 && ((cur_mask >> bit) & 1ull)) { hit = true; live = false; break; }
                 if (wk > hk) { live = false; break; }
@@ -473,21 +481,41 @@ VRT_DEV void traverse_cells(const TraceParams &P, float rox, float roy, float ro
             }
         }
     }
-    H.hit = hit ? 1 : 0; H.capped = 0; H.block_id = 0; H.k = 0; H.sk = 0;
-    if (hit) {
-        H.k = k; H.sk = k == 0 ? (px ? 1 : -1) : (k == 1 ? (py ? 1 : -1) : (pz ? 1 : -1));
-        // t as the reference computes it, in the unmirrored frame (see traverse_skip)
-        const int   pk = k == 0 ? (wx ^ smx) + lox + (px ? 0 : 1)
-                       : (k == 1 ? (wy ^ smy) + loy + (py ? 0 : 1) : (wz ^ smz) + loz + (pz ? 0 : 1));
-        const float th = ((float)pk - (k == 0 ? rox : (k == 1 ? roy : roz))) * (k == 0 ? invx : (k == 1 ? invy : invz));
-        H.t = th;
-        H.hx = rox + rdx * th; H.hy = roy + rdy * th; H.hz = roz + rdz * th;
-        H.block_id = load_block<T>(P, (wx ^ smx) + lox, (wy ^ smy) + loy, (wz ^ smz) + loz);
-    } else {
-        H.t = -1.0f; H.hx = H.hy = H.hz = 0.0f;
+
+    // outputs of a ray that has ended (live == false) after a successful begin()
+    VRT_DEV void finish(const TraceParams &P, float rox, float roy, float roz, float rdx, float rdy, float rdz,
+                        int lox, int loy, int loz, RayHit &H) const
+    {
+        H.hit = hit ? 1 : 0; H.capped = 0; H.block_id = 0; H.k = 0; H.sk = 0;
+        const int ax = (wx ^ smx) + lox, ay = (wy ^ smy) + loy, az = (wz ^ smz) + loz;
+        if (hit) {
+            H.k = k; H.sk = k == 0 ? (1 | smx) : (k == 1 ? (1 | smy) : (1 | smz));
+            // t as the reference computes it, in the unmirrored frame (see traverse_skip)
+            const int   pk = k == 0 ? ax - smx : (k == 1 ? ay - smy : az - smz);  // the entry plane: a + (s < 0)
+            const float th = ((float)pk - (k == 0 ? rox : (k == 1 ? roy : roz))) *
+                             (1.0f / (k == 0 ? rdx : (k == 1 ? rdy : rdz)));
+            H.t = th;
+            H.hx = rox + rdx * th; H.hy = roy + rdy * th; H.hz = roz + rdz * th;
+            H.block_id = load_block<T>(P, ax, ay, az);
+        } else {
+            H.t = -1.0f; H.hx = H.hy = H.hz = 0.0f;
+        }
+        H.vx = ax; H.vy = ay; H.vz = az;
+        H.steps = (unsigned)(wx + wy + wz - w0); H.iters = iters; H.work = work;
     }
-    H.vx = (wx ^ smx) + lox; H.vy = (wy ^ smy) + loy; H.vz = (wz ^ smz) + loz;
-    H.steps = (unsigned)(wx + wy + wz - w0); H.iters = iters; H.work = work;
+};
+
+template <typename T, bool POW2>
+VRT_DEV void traverse_cells(const TraceParams &P, float rox, float roy, float roz, float rdx, float rdy,
+                            float rdz, int lox, int loy, int loz, int upx, int upy, int upz, RayHit &H)
+{
+    CellRay<T, POW2> ray;
+    if (!ray.begin(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz)) {
+        traverse_literal<T, false>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
+        return;
+    }
+    while (ray.live) ray.trip(P);
+    ray.finish(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, H);
 }
 
 // picks the traversal for this launch (wave uniform)

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Long parity run (not part of pytest): many random poses over the procedural terrain, full frames,
+every output plane of the HIP skip kernel against the CPU oracle, bit for bit.
+usage: soak_parity.py [poses per world, default 40] [seed]   -> one summary line per world + total"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import oracle_lib as O
+from raytracing_amd import GraphicsCore, Player, TRACE_SKIP, VOXEL_PACKED_U8, VOXEL_REF_U16U16, scenes
+
+poses = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+PLANES = ("bgra8", "voxel", "face", "steps", "t", "hit_point", "rgba")
+total_px = total_bad = 0
+t_start = time.time()
+for n, fmt, dtype, w, h in [(160, VOXEL_REF_U16U16, np.uint16, 640, 480), (256, VOXEL_PACKED_U8, np.uint8, 960, 540),
+                            (1024, VOXEL_PACKED_U8, np.uint8, 1920, 1080)]:
+    centre = np.array([rng.uniform(-200, 200), 20.0, rng.uniform(-200, 200)], np.float32)
+    wmin = scenes.window_min(centre, n)
+    with GraphicsCore(grid_n=n, voxel_format=fmt, trace_mode=TRACE_SKIP) as g:
+        g.generate_window(wmin)
+        world = O.World(g.download_world())
+        base_chunk = scenes.chunk_of(centre)
+        bad = px = 0
+        for i in range(poses):
+            # any position inside the chunk the window was built for, any yaw, pitch from straight down to up
+            pos = (np.array(base_chunk, np.float32) * 32 + rng.uniform(0.01, 31.99, 3)).astype(np.float32)
+            if i % 3 == 0: pos[1] = np.float32(base_chunk[1] * 32 + rng.uniform(0.01, 12.0))   # near / under the surface
+            p = Player.at(pos, float(rng.uniform(-3.2, 3.2)), float(rng.uniform(-1.5, 1.5)))
+            cam = scenes.cam16(p)
+            got = g.trace(cam, w, h)
+            want = O.trace(world, cam, w, h)
+            for k in PLANES:
+                a, b = got[k], want[k]
+                if a.dtype == np.float32: a, b = a.view(np.uint32), b.view(np.uint32)
+                d = int((a != b).sum())
+                if d:
+                    bad += d
+                    print(f"MISMATCH n={n} pose {i} plane {k}: {d} elements, pos={pos.tolist()} look={p.look_direction}", flush=True)
+            px += w * h
+            if i % 10 == 9: print(f"  n={n}: {i + 1} poses, {bad} mismatching elements, {time.time() - t_start:.0f} s", flush=True)
+        print(f"world n={n} {w}x{h}: {poses} poses, {px} pixels, {len(PLANES)} planes each, mismatching elements: {bad}", flush=True)
+        total_px += px; total_bad += bad
+print(f"TOTAL: {total_px} pixels compared on {len(PLANES)} planes, mismatching elements: {total_bad}")
+sys.exit(1 if total_bad else 0)

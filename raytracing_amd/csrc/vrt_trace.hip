@@ -518,14 +518,18 @@ VRT_DEV void traverse_cells(const TraceParams &P, float rox, float roy, float ro
     ray.finish(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, H);
 }
 
-// picks the traversal for this launch (wave uniform)
-template <typename T>
+// The traversal a launch runs is fixed on the host (one kernel instance per form keeps the uniform
+// state of the other forms out of the scalar registers):
+//   FORM_CAPPED  one step per trip with the step cap tested (max_steps < 3n)
+//   FORM_POW2    two-phase loop, texel wrap by mask;   FORM_ANY_N  two-phase loop, wrap by subtraction
+enum { FORM_CAPPED = 0, FORM_POW2 = 1, FORM_ANY_N = 2 };
+
+template <typename T, int FORM>
 VRT_DEV void traverse_auto(const TraceParams &P, float rox, float roy, float roz, float rdx, float rdy,
                            float rdz, int lox, int loy, int loz, int upx, int upy, int upz, RayHit &H)
 {
-    if (P.need_cap) traverse_skip<T>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
-    else if (P.n_pow2_mask >= 0) traverse_cells<T, true>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
-    else traverse_cells<T, false>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
+    if (FORM == FORM_CAPPED) traverse_skip<T>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
+    else traverse_cells<T, FORM == FORM_POW2>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
 }
 
 // ---------------------------------------------------------------------------
@@ -723,7 +727,7 @@ __global__ __launch_bounds__(256) void k_trace_literal(const TraceParams P)
 }
 
 // (eight wavefronts per SIMD, i.e. at most 64 VGPRs: measured 1.8 % faster than the 65 the compiler takes unasked)
-template <typename T>
+template <typename T, int FORM>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_trace_skip(const TraceParams P)
 {
     const unsigned by = sched_row(P);
@@ -739,7 +743,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         // loaded area (raytrace.glsl:19-24), evaluated once per frame on the host
         const int lox = P.lo[0], loy = P.lo[1], loz = P.lo[2], upx = P.up[0], upy = P.up[1], upz = P.up[2];
         RayHit H;
-        traverse_auto<T>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
+        traverse_auto<T, FORM>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
         work = H.work;
         finish_pixel(P, gx, gy, (size_t)q * P.w + col, H);
 #ifdef VRT_DIAG_CLOCK
@@ -798,7 +802,7 @@ VRT_DEV void secondary_dir(unsigned pixel_index, unsigned index, int face, float
     dz = k == 2 ? nz : (k == 1 ? tx : ty);
 }
 
-template <typename T>
+template <typename T, int FORM>
 __global__ __launch_bounds__(256) void k_trace_secondary(const TraceParams P, uint8_t *shadow, uint8_t *ao, uint32_t *sec_steps)
 {
     const unsigned by = sched_row(P);
@@ -811,7 +815,7 @@ __global__ __launch_bounds__(256) void k_trace_secondary(const TraceParams P, ui
         // loaded area (raytrace.glsl:19-24), evaluated once per frame on the host
         const int lox = P.lo[0], loy = P.lo[1], loz = P.lo[2], upx = P.up[0], upy = P.up[1], upz = P.up[2];
         RayHit H;
-        traverse_auto<T>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
+        traverse_auto<T, FORM>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
         unsigned sh = 0, occ = 0, st = 0;
         work = H.work;
         if (H.hit) {
@@ -824,7 +828,7 @@ __global__ __launch_bounds__(256) void k_trace_secondary(const TraceParams P, ui
                 float sdx, sdy, sdz;
                 secondary_dir(row * P.w + col, s, face, sdx, sdy, sdz);
                 RayHit S;
-                traverse_auto<T>(P, sox, soy, soz, sdx, sdy, sdz, lox, loy, loz, upx, upy, upz, S);
+                traverse_auto<T, FORM>(P, sox, soy, soz, sdx, sdy, sdz, lox, loy, loz, upx, upy, upz, S);
                 st += S.steps;
                 work += S.work;
                 if (S.hit) { if (s == 0) sh = 1; else ++occ; }
@@ -844,6 +848,11 @@ __global__ __launch_bounds__(256) void k_trace_secondary(const TraceParams P, ui
             if (first == 0) sched_plan(P);
         }
     }
+}
+
+static int trace_form(const TraceParams &p)
+{
+    return p.need_cap ? FORM_CAPPED : (p.n_pow2_mask >= 0 ? FORM_POW2 : FORM_ANY_N);
 }
 
 static dim3 trace_grid(const TraceParams &p)
@@ -871,8 +880,14 @@ hipError_t launch_trace_secondary(const TraceParams &p, int voxel_bytes, uint8_t
 {
     if (p.rows.rows == 0 || p.w == 0) return hipSuccess;
     const dim3 grid = trace_grid(p), block(256);
-    if (voxel_bytes == 1) k_trace_secondary<uint8_t><<<grid, block, 0, s>>>(p, shadow, ao, sec_steps);
-    else k_trace_secondary<uint16_t><<<grid, block, 0, s>>>(p, shadow, ao, sec_steps);
+    const int form = trace_form(p);
+#define VRT_LAUNCH_SECONDARY(T)                                                                              \
+    (form == FORM_CAPPED ? k_trace_secondary<T, FORM_CAPPED><<<grid, block, 0, s>>>(p, shadow, ao, sec_steps) \
+     : form == FORM_POW2 ? k_trace_secondary<T, FORM_POW2><<<grid, block, 0, s>>>(p, shadow, ao, sec_steps)   \
+                         : k_trace_secondary<T, FORM_ANY_N><<<grid, block, 0, s>>>(p, shadow, ao, sec_steps))
+    if (voxel_bytes == 1) VRT_LAUNCH_SECONDARY(uint8_t);
+    else VRT_LAUNCH_SECONDARY(uint16_t);
+#undef VRT_LAUNCH_SECONDARY
     return hipGetLastError();
 }
 
@@ -880,8 +895,14 @@ hipError_t launch_trace_skip(const TraceParams &p, int voxel_bytes, hipStream_t 
 {
     if (p.rows.rows == 0 || p.w == 0) return hipSuccess;
     const dim3 grid = trace_grid(p), block(256);
-    if (voxel_bytes == 1) k_trace_skip<uint8_t><<<grid, block, 0, s>>>(p);
-    else k_trace_skip<uint16_t><<<grid, block, 0, s>>>(p);
+    const int form = trace_form(p);
+#define VRT_LAUNCH_SKIP(T)                                                              \
+    (form == FORM_CAPPED ? k_trace_skip<T, FORM_CAPPED><<<grid, block, 0, s>>>(p)         \
+     : form == FORM_POW2 ? k_trace_skip<T, FORM_POW2><<<grid, block, 0, s>>>(p)           \
+                         : k_trace_skip<T, FORM_ANY_N><<<grid, block, 0, s>>>(p))
+    if (voxel_bytes == 1) VRT_LAUNCH_SKIP(uint8_t);
+    else VRT_LAUNCH_SKIP(uint16_t);
+#undef VRT_LAUNCH_SKIP
     return hipGetLastError();
 }
 

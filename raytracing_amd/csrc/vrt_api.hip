@@ -251,6 +251,7 @@ int prepare_trace(vrt_ctx *c, const float *cam, uint32_t w, uint32_t h, const vr
     p.ncy_off = (float)h / (float)w * 0.5f;
     p.n = (int)c->n;
     p.n_pow2_mask = (c->n & (c->n - 1)) == 0 ? (int)c->n - 1 : -1;
+    for (uint32_t v = c->n / 4; v > 1; v >>= 1) p.nc_log2 += 1;
     p.max_steps = c->max_steps;
     p.tile_log2h = 2;
     p.need_cap = c->max_steps < 3u * c->n ? 1u : 0u;

@@ -45,6 +45,7 @@ struct TraceParams {
     // lo = floor(ro/32)*32 + 16 - n/2, up = lo + n - 1, off = rem_euclid(lo, n)
     int32_t  lo[3], up[3], off[3];
     int32_t  n_pow2_mask;  // n-1 if n is a power of two, else -1
+    int32_t  nc_log2;      // log2(n / 4) if n is a power of two
     uint32_t max_steps;
     uint32_t tile_log2h;   // wave tile is (64 >> tile_log2h) x (1 << tile_log2h) pixels, 0..6
     uint32_t need_cap;     // max_steps can end a regular ray (max_steps < 3n): test it in the skip loop

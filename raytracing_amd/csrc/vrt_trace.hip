@@ -353,7 +353,9 @@ struct CellRay {
         } else {
             qx -= qx >= n ? n : 0; qy -= qy >= n ? n : 0; qz -= qz >= n ? n : 0;
         }
-        const unsigned cell = (unsigned)(((qz >> 2) * nc + (qy >> 2)) * nc + (qx >> 2));
+        // (shifts for a power of two: the 64-bit multiply-adds of the general form run at quarter rate)
+        const unsigned cell = POW2 ? (unsigned)(((((qz >> 2) << P.nc_log2) | (qy >> 2)) << P.nc_log2) | (qx >> 2))
+                                   : (unsigned)(((qz >> 2) * nc + (qy >> 2)) * nc + (qx >> 2));
         const uint4 r = P.cells[cell];
         info     = r.x;
         cur_mask = (uint64_t)r.x | ((uint64_t)r.y << 32);

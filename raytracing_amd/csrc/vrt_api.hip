@@ -59,6 +59,14 @@ struct vrt_ctx {
     int         pyr_offcy    = -1;       // vertical window offset (cells) the pyramid entries were built for
     bool        skip_valid   = false;
     uint32_t   *d_flag       = nullptr;
+    // measurement knobs, read from the environment once, when the context is created
+    //   VRT_TILE_LOG2H=k    wave tile of (64 >> k) x (1 << k) pixels instead of 16 x 4
+    //   VRT_NO_ROW_ORDER=1  workgroup rows always top to bottom
+    //   VRT_ROW_BLOCK0=r    workgroup rows always start at row block r
+    //   VRT_SCHED_DEBUG=1   print what each launch measured for the dispatch order (synchronises)
+    uint32_t    knob_tile_log2h = 2;
+    bool        knob_no_row_order = false, knob_sched_debug = false;
+    int32_t     knob_row_block0 = -1;
     // dispatch-order feedback of the skip kernels (vrt::RowSched)
     uint32_t   *d_sched      = nullptr;       // start[2] | row_longest[2][256] | cost[2][kSchedCapacity]
     uint32_t    sched_gen    = 0;             // generation of the last skip launch, 1..4095
@@ -167,12 +175,11 @@ int attach_row_sched(vrt_ctx *c, vrt::TraceParams &p, uint32_t kind)
 {
     p.sched = vrt::RowSched{};
     p.sched.fixed_start = -1;
-    { const char *v = std::getenv("VRT_ROW_BLOCK0"); if (v && v[0] != 'x') { p.sched.fixed_start = std::atoi(v); c->sched_sig[0] = 0; return VRT_OK; } }  // A/B only
+    if (c->knob_row_block0 >= 0) { p.sched.fixed_start = c->knob_row_block0; c->sched_sig[0] = 0; return VRT_OK; }
     const uint32_t block_h = 4u << p.tile_log2h;
     const uint32_t grid_y = (p.rows.rows + block_h - 1) / block_h;
-    const char *off = std::getenv("VRT_NO_ROW_ORDER");  // "1": rows top to bottom, for A/B measurements
     const uint32_t grid_x = (p.w + (64u >> p.tile_log2h) - 1) / (64u >> p.tile_log2h);
-    if (!c->d_sched || grid_y == 0 || grid_y > kSchedRows || (uint64_t)grid_x * grid_y * 4 > kSchedCapacity || (off && off[0] == '1')) {
+    if (!c->d_sched || grid_y == 0 || grid_y > kSchedRows || (uint64_t)grid_x * grid_y * 4 > kSchedCapacity || c->knob_no_row_order) {
         c->sched_sig[0] = 0;
         return VRT_OK;
     }
@@ -181,7 +188,7 @@ int attach_row_sched(vrt_ctx *c, vrt::TraceParams &p, uint32_t kind)
         ((uint64_t)p.rows.y0 << 32) | (uint64_t)p.rows.rows,
         ((uint64_t)p.rows.strip_h << 40) | ((uint64_t)p.rows.part << 20) | (uint64_t)p.rows.parts,
         (uint64_t)(horizon_packed_row(p.m, p.w, p.h, p.rows) / block_h)};
-    if (std::getenv("VRT_SCHED_DEBUG") && c->sched_gen > 0) {  // diagnostic: what the last launch measured
+    if (c->knob_sched_debug && c->sched_gen > 0) {  // diagnostic: what the last launch measured
         std::vector<uint32_t> hbuf(kSchedHead + 2 * (size_t)kSchedCapacity);
         HIP_TRY(hipStreamSynchronize(c->stream));
         HIP_TRY(hipMemcpy(hbuf.data(), c->d_sched, kSchedBytes, hipMemcpyDeviceToHost));
@@ -253,7 +260,7 @@ int prepare_trace(vrt_ctx *c, const float *cam, uint32_t w, uint32_t h, const vr
     p.n_pow2_mask = (c->n & (c->n - 1)) == 0 ? (int)c->n - 1 : -1;
     for (uint32_t v = c->n / 4; v > 1; v >>= 1) p.nc_log2 += 1;
     p.max_steps = c->max_steps;
-    p.tile_log2h = 2;
+    p.tile_log2h = c->knob_tile_log2h;
     p.need_cap = c->max_steps < 3u * c->n ? 1u : 0u;
     for (int k = 0; k < 3; ++k) {
         const int n = (int)c->n;
@@ -263,7 +270,6 @@ int prepare_trace(vrt_ctx *c, const float *cam, uint32_t w, uint32_t h, const vr
         int r = p.lo[k] % n;
         p.off[k] = r < 0 ? r + n : r;
     }
-    { const char *v = std::getenv("VRT_TILE_LOG2H"); if (v) p.tile_log2h = (uint32_t)std::atoi(v) % 7u; }  // A/B only
     p.block = c->d_block;
     p.dist = c->dist_nonzero ? c->d_dist : nullptr;
     p.cells = c->d_cells; p.nc = (int)c->n / 4;
@@ -354,6 +360,10 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out)
     c->max_steps   = cfg->max_steps ? cfg->max_steps : 4 * cfg->grid_n;
     c->trace_mode  = cfg->trace_mode;
     for (int i = 0; i < kEventRing; ++i) { c->ev0[i] = nullptr; c->ev1[i] = nullptr; }
+    if (const char *v = std::getenv("VRT_TILE_LOG2H")) c->knob_tile_log2h = (uint32_t)std::atoi(v) % 7u;
+    if (const char *v = std::getenv("VRT_NO_ROW_ORDER")) c->knob_no_row_order = v[0] == '1';
+    if (const char *v = std::getenv("VRT_ROW_BLOCK0")) c->knob_row_block0 = std::atoi(v);
+    if (const char *v = std::getenv("VRT_SCHED_DEBUG")) c->knob_sched_debug = v[0] == '1';
     auto bail = [&](int code) { vrt_destroy(c); return code; };
 #define TRY_OR_BAIL(expr)                                                                                     \
     do {                                                                                                      \

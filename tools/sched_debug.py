@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Diagnostic: with VRT_SCHED_DEBUG=1 in the environment the library prints, before every skip launch,
+the start rows planned so far and the trip count per workgroup row the previous launch recorded."""
 import os, sys
 sys.path.insert(0, "/root/repo")
 import torch

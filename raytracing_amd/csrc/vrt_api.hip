@@ -56,6 +56,7 @@ struct vrt_ctx {
     // skip structure
     uint4      *d_cells      = nullptr;  // (n/4)^3 records: occupancy mask + octant distances
     uint16_t   *d_tops       = nullptr;  // column-top pyramid scratch, 2 * (n/4)^2
+    uint2      *d_pyr        = nullptr;  // (n/4)^3 words: column-top pyramid at voxel precision
     int         pyr_offcy    = -1;       // vertical window offset (cells) the pyramid entries were built for
     bool        skip_valid   = false;
     uint32_t   *d_flag       = nullptr;
@@ -109,6 +110,7 @@ int ensure_skip_structure(vrt_ctx *c, int offcy)
     if (!c->skip_valid) {
         if (!c->d_cells) HIP_TRY(hipMalloc(&c->d_cells, cells(c) * sizeof(uint4)));
         if (!c->d_tops) HIP_TRY(hipMalloc(&c->d_tops, 2 * (size_t)(c->n / 4) * (c->n / 4) * sizeof(uint16_t)));
+        if (!c->d_pyr) HIP_TRY(hipMalloc(&c->d_pyr, cells(c) * sizeof(uint2)));
         // scratch for the separable distance passes: released again, the build is not a hot path
         uint8_t *tmp = nullptr;
         HIP_TRY(hipMalloc(&tmp, 11 * cells(c)));
@@ -122,6 +124,7 @@ int ensure_skip_structure(vrt_ctx *c, int offcy)
     }
     if (c->pyr_offcy != offcy) {
         HIP_TRY(vrt::launch_build_pyramid(c->d_cells, (int)c->n / 4, offcy, c->d_tops, c->stream));
+        HIP_TRY(vrt::launch_build_voxel_pyramid(c->d_cells, (int)c->n / 4, offcy, c->d_tops, c->d_pyr, c->stream));
         c->pyr_offcy = offcy;
     }
     return VRT_OK;
@@ -272,7 +275,7 @@ int prepare_trace(vrt_ctx *c, const float *cam, uint32_t w, uint32_t h, const vr
     }
     p.block = c->d_block;
     p.dist = c->dist_nonzero ? c->d_dist : nullptr;
-    p.cells = c->d_cells; p.nc = (int)c->n / 4;
+    p.cells = c->d_cells; p.nc = (int)c->n / 4; p.pyr = c->d_pyr;
     return VRT_OK;
 }
 
@@ -394,7 +397,7 @@ int vrt_destroy(vrt_ctx *c)
         if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]);
         if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]);
     }
-    void *bufs[] = {c->d_block, c->d_dist, c->d_cells, c->d_tops, c->d_flag, c->d_sched, c->d_stage};
+    void *bufs[] = {c->d_block, c->d_dist, c->d_cells, c->d_tops, c->d_pyr, c->d_flag, c->d_sched, c->d_stage};
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

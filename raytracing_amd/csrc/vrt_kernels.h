@@ -65,6 +65,11 @@ struct TraceParams {
     //          that octant; 0 = the cell is non-empty, cap 255
     const uint4 *cells;
     int32_t  nc;                // n / 4
+    // column-top pyramid at voxel precision, one 64-bit word per cell (any cell, empty or not): for
+    // each of the cell's four voxel levels j a 16-bit entry (L + 1) << 12 | drop -- the aligned block of
+    // 2^L x 2^L cell columns around the cell holds no voxel at or above window level (4*layer + j) - drop,
+    // L the largest such level and drop capped at 4095; 0 = not even the cell's own column qualifies
+    const uint2 *pyr;
     // outputs (device pointers, any may be null)
     uint8_t  *bgra8;
     int32_t  *voxel;
@@ -88,6 +93,8 @@ hipError_t launch_terrain(void *block, int voxel_bytes, int n, int x0, int y0, i
 hipError_t launch_build_cells(const void *block, int voxel_bytes, int n, uint4 *cells, uint8_t *tmp, hipStream_t s);
 // tops: scratch of at least 2 * nc * nc uint16_t; offcy = rem_euclid(lower_y, n) / 4
 hipError_t launch_build_pyramid(uint4 *cells, int nc, int offcy, uint16_t *tops, hipStream_t s);
+// same scratch; pyr = nc^3 words
+hipError_t launch_build_voxel_pyramid(const uint4 *cells, int nc, int offcy, uint16_t *tops, uint2 *pyr, hipStream_t s);
 hipError_t launch_any_nonzero_u16(const uint16_t *p, size_t count, uint32_t *flag, hipStream_t s);
 
 }  // namespace vrt

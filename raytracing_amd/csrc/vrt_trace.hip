@@ -340,7 +340,8 @@ struct CellRay {
     int   dshift;  // bit 5: the octant byte lives in the record's .w word
     // state
     int      wx, wy, wz, w0, k, d, bit, qx, qy, qz;
-    unsigned info, work, iters;
+    unsigned pyr_lo, pyr_hi;  // the cell's word of the voxel-precision column-top pyramid
+    unsigned work, iters;
     uint64_t cur_mask;
     bool     live, hit;
 
@@ -357,11 +358,15 @@ struct CellRay {
         const unsigned cell = POW2 ? (unsigned)(((((qz >> 2) << P.nc_log2) | (qy >> 2)) << P.nc_log2) | (qx >> 2))
                                    : (unsigned)(((qz >> 2) * nc + (qy >> 2)) * nc + (qx >> 2));
         const uint4 r = P.cells[cell];
-        info     = r.x;
+        const uint2 pw = P.pyr[cell];
         cur_mask = (uint64_t)r.x | ((uint64_t)r.y << 32);
         d        = (int)((((dshift & 32) ? r.w : r.z) >> (dshift & 31)) & 0xffu);
         bit      = ((qz & 3) << 4) | ((qy & 3) << 2) | (qx & 3);  // off is a multiple of 4
+        pyr_lo = pw.x; pyr_hi = pw.y;
     }
+
+    // pyramid entry of the current voxel's level (0: none); `bit` carries the level in bits 2..3
+    VRT_DEV unsigned entry() const { return (((bit & 8) ? pyr_hi : pyr_lo) >> ((bit & 4) << 2)) & 0xffffu; }
 
     // false: the direction has a zero or non-finite component and the ray takes the literal loop
     VRT_DEV bool begin(const TraceParams &P, float rox, float roy, float roz, float rdx, float rdy, float rdz,
@@ -371,7 +376,7 @@ struct CellRay {
         const float big = 0x1.0p100f;
         const bool regular = (rdx != 0.0f) && (rdy != 0.0f) && (rdz != 0.0f) && (fabsf(invx) < big) &&
                              (fabsf(invy) < big) && (fabsf(invz) < big);
-        live = false; hit = false; k = 0; d = 0; info = 0; cur_mask = 0; work = 0; iters = 0; bit = 0;
+        live = false; hit = false; k = 0; d = 0; pyr_lo = pyr_hi = 0; cur_mask = 0; work = 0; iters = 0; bit = 0;
         qx = qy = qz = 0;
         if (!regular) return false;
         const int n = P.n;
@@ -410,15 +415,20 @@ struct CellRay {
 #ifdef VRT_DIAG_ITERS
         iters += 1u;
 #endif
-        if (d != 0) {
-            // ---- phase A: cross the empty box that starts at this cell
+        unsigned e = entry();
+        if (d != 0 || e != 0) {
+            // ---- phase A: cross an empty box that holds the current voxel: the column-top block of the
+            // voxel's level (also inside a non-empty cell, above its solid voxels) or the octant cube
             int fwx, fwy, fwz;  // last anchor of the box on each axis
-            const int lvl = (int)(info & 0xffu);
-            if (lvl > 0 && (1 << lvl) > d) {
+            const int lvl = (int)(e >> 12) - 1;
+            if (e != 0 && (1 << lvl) > d) {
                 const int m4 = (4 << lvl) - 1;
-                fwx = m4 >= n - 1 ? whix : min(wx + ((qx ^ ~smx) & m4), whix);
-                fwz = m4 >= n - 1 ? whiz : min(wz + ((qz ^ ~smz) & m4), whiz);
-                fwy = smy == 0 ? whiy : min(~(int)((info >> 8) << 2), whiy);
+                // texel of the current anchor up to a multiple of n, which is a multiple of the block width
+                // (qx, qz date from the last cell lookup and may lie some unit steps back)
+                const int ux = (wx ^ smx) + P.off[0], uz = (wz ^ smz) + P.off[2];
+                fwx = m4 >= n - 1 ? whix : min(wx + ((ux ^ ~smx) & m4), whix);
+                fwz = m4 >= n - 1 ? whiz : min(wz + ((uz ^ ~smz) & m4), whiz);
+                fwy = smy == 0 ? whiy : min(wy + (int)(e & 0xfffu), whiy);
             } else {
                 const int r4 = (d - 1) << 2;
                 fwx = min((wx | 3) + r4, whix);
@@ -459,8 +469,9 @@ struct CellRay {
             locate(P);  // a box ends at a cell boundary on its exit axis
             if (d == 0 && ((cur_mask >> bit) & 1ull)) { hit = true; live = false; }
             else if (wk > hk) live = false;
+            e = entry();
         }
-        if (live && d == 0) {
+        if (live && d == 0 && e == 0) {
             // ---- phase B: a few unit steps through the non-empty cell(s)
             // change of the mask bit index (z*16 + y*4 + x of the unmirrored voxel) per unit step
             const int dbx = 1 | smx, dby = 4 ^ (smy & ~7), dbz = 16 ^ (smz & ~31);  // +-1, +-4, +-16
@@ -479,7 +490,7 @@ struct CellRay {
                 else bit += k == 0 ? dbx : (k == 1 ? dby : dbz);
                 if (d == 0 && ((cur_mask >> bit) & 1ull)) { hit = true; live = false; break; }
                 if (wk > hk) { live = false; break; }
-                if (d != 0) break;  // an empty cell: back to phase A
+                if (d != 0 || entry() != 0) break;  // an empty box again: back to phase A
             }
         }
     }

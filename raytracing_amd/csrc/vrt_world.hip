@@ -326,6 +326,71 @@ hipError_t launch_build_pyramid(uint4 *cells, int nc, int offcy, uint16_t *tops,
 }
 
 // ---------------------------------------------------------------------------
+// column-top pyramid at voxel precision (TraceParams::pyr)
+// ---------------------------------------------------------------------------
+// vtops[0][tcz][tcx] = window level (voxels from the bottom of the loaded window) just above the highest
+// solid voxel of the 4x4 voxel columns of cell column (tcx, tcz), 0 if they are empty.
+__global__ __launch_bounds__(256) void k_column_vtops(const uint4 *cells, int nc, int offcy, uint16_t *tops0)
+{
+    const int tcx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int tcz = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (tcx >= nc || tcz >= nc) return;
+    int v = 0;
+    for (int wl = nc - 1; wl >= 0; --wl) {
+        int tcy = wl + offcy;
+        tcy -= tcy >= nc ? nc : 0;
+        const uint4 rec = cells[((size_t)tcz * nc + tcy) * nc + tcx];
+        if ((rec.z & 0xffu) != 0) continue;  // empty cell
+        const uint64_t m = (uint64_t)rec.x | ((uint64_t)rec.y << 32);
+        int y = 3;
+        while (y > 0 && (m & (0x000F000F000F000Full << (4 * y))) == 0) --y;
+        v = 4 * wl + y + 1;
+        break;
+    }
+    tops0[(size_t)tcz * nc + tcx] = (uint16_t)v;
+}
+
+__global__ __launch_bounds__(256) void k_voxel_pyramid(int nc, int offcy, PyramidLevels pyr, uint2 *out)
+{
+    const int tcx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int tcy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int tcz = blockIdx.z;
+    if (tcx >= nc || tcy >= nc) return;
+    int wl = tcy - offcy;
+    wl += wl < 0 ? nc : 0;
+    unsigned e[4];
+    for (int j = 0; j < 4; ++j) {
+        const int v = 4 * wl + j;
+        unsigned best = 0;
+        for (int L = 0; L <= pyr.levels; ++L) {
+            const int t = (int)pyr.tops[L][(size_t)(tcz >> L) * pyr.size[L] + (tcx >> L)];
+            if (t <= v) best = ((unsigned)(L + 1) << 12) | (unsigned)min(v - t, 4095); else break;  // tops grow with L
+        }
+        e[j] = best;
+    }
+    out[((size_t)tcz * nc + tcy) * nc + tcx] = make_uint2(e[0] | (e[1] << 16), e[2] | (e[3] << 16));
+}
+
+hipError_t launch_build_voxel_pyramid(const uint4 *cells, int nc, int offcy, uint16_t *tops, uint2 *out, hipStream_t s)
+{
+    const dim3 blockdim(256);
+    PyramidLevels pyr{};
+    uint16_t *level = tops;
+    int       size = nc;
+    k_column_vtops<<<dim3((nc + 63) / 64, (nc + 3) / 4), blockdim, 0, s>>>(cells, nc, offcy, level);
+    pyr.tops[0] = level; pyr.size[0] = size; pyr.levels = 0;
+    for (int L = 1; L <= 8; ++L) {
+        if (nc % (1 << L) != 0) break;  // blocks are aligned in torus cell coordinates
+        uint16_t *coarse = level + (size_t)size * size;
+        k_tops_reduce<<<dim3(((nc >> L) + 63) / 64, ((nc >> L) + 3) / 4), blockdim, 0, s>>>(level, size, coarse, nc >> L);
+        level = coarse; size = nc >> L;
+        pyr.tops[L] = level; pyr.size[L] = size; pyr.levels = L;
+    }
+    k_voxel_pyramid<<<dim3((nc + 63) / 64, (nc + 3) / 4, nc), blockdim, 0, s>>>(nc, offcy, pyr, out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_any_nonzero(const uint16_t *p, size_t count, uint32_t *flag)
 {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;

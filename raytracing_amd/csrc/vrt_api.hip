@@ -57,6 +57,10 @@ struct vrt_ctx {
     uint4      *d_cells      = nullptr;  // (n/4)^3 records: occupancy mask + octant distances
     uint16_t   *d_tops       = nullptr;  // column-top pyramid scratch, 2 * (n/4)^2
     uint2      *d_pyr        = nullptr;  // (n/4)^3 words: column-top pyramid at voxel precision
+    // per-frame tables (TraceParams::ncx, ncy, sin2): ncx[16384] | ncy[16385] | sin2[3][grid_n + 8]
+    float      *d_tables     = nullptr;
+    uint32_t    tab_w = 0, tab_h = 0;    // frame the tables were filled for (0: none)
+    int32_t     tab_base[3]  = {0, 0, 0};
     int         pyr_offcy    = -1;       // vertical window offset (cells) the pyramid entries were built for
     bool        skip_valid   = false;
     uint32_t   *d_flag       = nullptr;
@@ -276,6 +280,20 @@ int prepare_trace(vrt_ctx *c, const float *cam, uint32_t w, uint32_t h, const vr
     p.block = c->d_block;
     p.dist = c->dist_nonzero ? c->d_dist : nullptr;
     p.cells = c->d_cells; p.nc = (int)c->n / 4; p.pyr = c->d_pyr;
+    {   // per-frame tables: refilled (one small launch) when the frame shape or the window position changes
+        constexpr uint32_t kMaxDim = 16384;
+        const uint32_t sin_len = c->n + 8;
+        if (!c->d_tables) HIP_TRY(hipMalloc(&c->d_tables, ((size_t)2 * kMaxDim + 1 + 3 * (size_t)sin_len) * sizeof(float)));
+        float *ncx = c->d_tables, *ncy = ncx + kMaxDim, *sin2 = ncy + kMaxDim + 1;
+        const int32_t base[3] = {p.lo[0] - 4, p.lo[1] - 4, p.lo[2] - 4};
+        if (c->tab_w != w || c->tab_h != h || std::memcmp(base, c->tab_base, sizeof base) != 0) {
+            HIP_TRY(vrt::launch_frame_tables(ncx, ncy, sin2, w, h, p.ncy_off, base, sin_len, c->stream));
+            c->tab_w = w; c->tab_h = h;
+            std::memcpy(c->tab_base, base, sizeof base);
+        }
+        p.ncx = ncx; p.ncy = ncy; p.sin2 = sin2; p.sin_len = sin_len;
+        std::memcpy(p.sin_base, base, sizeof base);
+    }
     return VRT_OK;
 }
 
@@ -397,7 +415,7 @@ int vrt_destroy(vrt_ctx *c)
         if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]);
         if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]);
     }
-    void *bufs[] = {c->d_block, c->d_dist, c->d_cells, c->d_tops, c->d_pyr, c->d_flag, c->d_sched, c->d_stage};
+    void *bufs[] = {c->d_block, c->d_dist, c->d_cells, c->d_tops, c->d_pyr, c->d_tables, c->d_flag, c->d_sched, c->d_stage};
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

@@ -70,6 +70,14 @@ struct TraceParams {
     // 2^L x 2^L cell columns around the cell holds no voxel at or above window level (4*layer + j) - drop,
     // L the largest such level and drop capped at 4095; 0 = not even the cell's own column qualifies
     const uint2 *pyr;
+    // per-frame tables (device memory, filled by launch_frame_tables with the kernels' own arithmetic;
+    // null = evaluate in place): the two divisions of raytrace.glsl:121 per column / per row, and the
+    // sine of raytrace.glsl:131 for every voxel coordinate a hit point can floor to
+    const float *ncx;       // [w]      float(gx) / float(w) - 0.5
+    const float *ncy;       // [h + 1]  float(gy) / float(h) - ncy_off, indexed by gy = h - row
+    const float *sin2;      // [3][sin_len]  canon_sin(2 * (sin_base[k] + i))
+    int32_t  sin_base[3];
+    uint32_t sin_len;
     // outputs (device pointers, any may be null)
     uint8_t  *bgra8;
     int32_t  *voxel;
@@ -95,6 +103,8 @@ hipError_t launch_build_cells(const void *block, int voxel_bytes, int n, uint4 *
 hipError_t launch_build_pyramid(uint4 *cells, int nc, int offcy, uint16_t *tops, hipStream_t s);
 // same scratch; pyr = nc^3 words
 hipError_t launch_build_voxel_pyramid(const uint4 *cells, int nc, int offcy, uint16_t *tops, uint2 *pyr, hipStream_t s);
+hipError_t launch_frame_tables(float *ncx, float *ncy, float *sin2, uint32_t w, uint32_t h, float ncy_off,
+                               const int32_t sin_base[3], uint32_t sin_len, hipStream_t s);
 hipError_t launch_any_nonzero_u16(const uint16_t *p, size_t count, uint32_t *flag, hipStream_t s);
 
 }  // namespace vrt

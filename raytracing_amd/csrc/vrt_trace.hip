@@ -679,8 +679,8 @@ VRT_DEV void sched_plan(const TraceParams &P)
 VRT_DEV void raygen(const TraceParams &P, unsigned gx, unsigned gy, float &rdx, float &rdy, float &rdz)
 {
     const float fw = (float)P.w, fh = (float)P.h;
-    const float ncx = (float)gx / fw - 0.5f;
-    const float ncy = (float)gy / fh - P.ncy_off;
+    const float ncx = P.ncx ? P.ncx[gx] : (float)gx / fw - 0.5f;
+    const float ncy = P.ncy ? P.ncy[gy] : (float)gy / fh - P.ncy_off;
     const float *m = P.m;
     const float d0 = ((ncx * m[0] + ncy * m[1]) + 1.0f * m[2]) + 1.0f * m[3];
     const float d1 = ((ncx * m[4] + ncy * m[5]) + 1.0f * m[6]) + 1.0f * m[7];
@@ -689,15 +689,52 @@ VRT_DEV void raygen(const TraceParams &P, unsigned gx, unsigned gy, float &rdx, 
     rdx = d0 / len; rdy = d1 / len; rdz = d2 / len;
 }
 
+// sin(floor(hit + 0.001) * 2) of raytrace.glsl:131 for axis k: from the frame's table when the floored
+// coordinate is in it (always, for a hit inside the loaded area), else evaluated
+VRT_DEV float shade_sine(const TraceParams &P, int k, float h)
+{
+    const float f = floorf(h + 0.001f);
+    if (P.sin2) {
+        const float i = f - (float)P.sin_base[k];  // exact; NaN (a degenerate ray) fails both tests
+        if (i >= 0.0f && i < (float)P.sin_len) return P.sin2[(unsigned)k * P.sin_len + (unsigned)f2i_small(i)];
+    }
+    return canon_sin(f * 2.0f);
+}
+
+// the same arithmetic, once per frame shape / window position instead of once per pixel
+__global__ __launch_bounds__(256) void k_frame_tables(float *ncx, float *ncy, float *sin2, unsigned w, unsigned h,
+                                                      float ncy_off, int b0, int b1, int b2, unsigned sin_len)
+{
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    const float fw = (float)w, fh = (float)h;
+    if (i < w) ncx[i] = (float)i / fw - 0.5f;
+    if (i <= h) ncy[i] = (float)i / fh - ncy_off;
+    if (i < sin_len) {
+        sin2[i]               = canon_sin((float)(b0 + (int)i) * 2.0f);
+        sin2[sin_len + i]     = canon_sin((float)(b1 + (int)i) * 2.0f);
+        sin2[2 * sin_len + i] = canon_sin((float)(b2 + (int)i) * 2.0f);
+    }
+}
+
+hipError_t launch_frame_tables(float *ncx, float *ncy, float *sin2, uint32_t w, uint32_t h, float ncy_off,
+                               const int32_t sin_base[3], uint32_t sin_len, hipStream_t s)
+{
+    unsigned count = w > h + 1 ? w : h + 1;
+    if (sin_len > count) count = sin_len;
+    k_frame_tables<<<(count + 255) / 256, 256, 0, s>>>(ncx, ncy, sin2, w, h, ncy_off, sin_base[0], sin_base[1],
+                                                        sin_base[2], sin_len);
+    return hipGetLastError();
+}
+
 // raytrace.glsl:129-133 + render.comp:9-13
 VRT_DEV void finish_pixel(const TraceParams &P, unsigned gx, unsigned gy, size_t i, const RayHit &H)
 {
     float r, g, b, a = 1.0f;
     if (H.hit) {
         const float nk = (float)(-H.sk);
-        r = (H.k == 0 ? nk : 0.0f) + 0.5f * canon_sin(floorf(H.hx + 0.001f) * 2.0f);
-        g = (H.k == 1 ? nk : 0.0f) + 0.5f * canon_sin(floorf(H.hy + 0.001f) * 2.0f);
-        b = (H.k == 2 ? nk : 0.0f) + 0.5f * canon_sin(floorf(H.hz + 0.001f) * 2.0f);
+        r = (H.k == 0 ? nk : 0.0f) + 0.5f * shade_sine(P, 0, H.hx);
+        g = (H.k == 1 ? nk : 0.0f) + 0.5f * shade_sine(P, 1, H.hy);
+        b = (H.k == 2 ? nk : 0.0f) + 0.5f * shade_sine(P, 2, H.hz);
     } else if (H.steps >= 1000u) {  // raytrace.glsl:73-75
         r = 0.2f; g = 1.0f; b = 0.8f;
     } else {

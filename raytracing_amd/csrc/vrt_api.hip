@@ -56,7 +56,7 @@ struct vrt_ctx {
     // skip structure
     uint4      *d_cells      = nullptr;  // (n/4)^3 records: occupancy mask + octant distances
     uint16_t   *d_tops       = nullptr;  // column-top pyramid scratch, 2 * (n/4)^2
-    uint2      *d_pyr        = nullptr;  // (n/4)^3 words: column-top pyramid at voxel precision
+    uint4      *d_pyr        = nullptr;  // (n/4)^3 x 16 B: column-top pyramid at voxel precision
     // per-frame tables (TraceParams::ncx, ncy, sin2): ncx[16384] | ncy[16385] | sin2[3][grid_n + 8]
     float      *d_tables     = nullptr;
     uint32_t    tab_w = 0, tab_h = 0;    // frame the tables were filled for (0: none)
@@ -114,7 +114,7 @@ int ensure_skip_structure(vrt_ctx *c, int offcy)
     if (!c->skip_valid) {
         if (!c->d_cells) HIP_TRY(hipMalloc(&c->d_cells, cells(c) * sizeof(uint4)));
         if (!c->d_tops) HIP_TRY(hipMalloc(&c->d_tops, 2 * (size_t)(c->n / 4) * (c->n / 4) * sizeof(uint16_t)));
-        if (!c->d_pyr) HIP_TRY(hipMalloc(&c->d_pyr, cells(c) * sizeof(uint2)));
+        if (!c->d_pyr) HIP_TRY(hipMalloc(&c->d_pyr, cells(c) * sizeof(uint4)));
         // scratch for the separable distance passes: released again, the build is not a hot path
         uint8_t *tmp = nullptr;
         HIP_TRY(hipMalloc(&tmp, 11 * cells(c)));

@@ -65,11 +65,12 @@ struct TraceParams {
     //          that octant; 0 = the cell is non-empty, cap 255
     const uint4 *cells;
     int32_t  nc;                // n / 4
-    // column-top pyramid at voxel precision, one 64-bit word per cell (any cell, empty or not): for
+    // column-top pyramid at voxel precision, two 64-bit words per cell (any cell, empty or not): for
     // each of the cell's four voxel levels j a 16-bit entry (L + 1) << 12 | drop -- the aligned block of
-    // 2^L x 2^L cell columns around the cell holds no voxel at or above window level (4*layer + j) - drop,
-    // L the largest such level and drop capped at 4095; 0 = not even the cell's own column qualifies
-    const uint2 *pyr;
+    // 2^L x 2^L cell columns around the cell holds no voxel at or above window level (4*layer + j) - drop
+    // (drop capped at 4095); 0 = not even the cell's own column qualifies.  .x,.y: the widest such block
+    // (read by rays that rise); .z,.w: the block the builder prefers for rays that descend.
+    const uint4 *pyr;
     // per-frame tables (device memory, filled by launch_frame_tables with the kernels' own arithmetic;
     // null = evaluate in place): the two divisions of raytrace.glsl:121 per column / per row, and the
     // sine of raytrace.glsl:131 for every voxel coordinate a hit point can floor to
@@ -102,7 +103,7 @@ hipError_t launch_build_cells(const void *block, int voxel_bytes, int n, uint4 *
 // tops: scratch of at least 2 * nc * nc uint16_t; offcy = rem_euclid(lower_y, n) / 4
 hipError_t launch_build_pyramid(uint4 *cells, int nc, int offcy, uint16_t *tops, hipStream_t s);
 // same scratch; pyr = nc^3 words
-hipError_t launch_build_voxel_pyramid(const uint4 *cells, int nc, int offcy, uint16_t *tops, uint2 *pyr, hipStream_t s);
+hipError_t launch_build_voxel_pyramid(const uint4 *cells, int nc, int offcy, uint16_t *tops, uint4 *pyr, hipStream_t s);
 hipError_t launch_frame_tables(float *ncx, float *ncy, float *sin2, uint32_t w, uint32_t h, float ncy_off,
                                const int32_t sin_base[3], uint32_t sin_len, hipStream_t s);
 hipError_t launch_any_nonzero_u16(const uint16_t *p, size_t count, uint32_t *flag, hipStream_t s);

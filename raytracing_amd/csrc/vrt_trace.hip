@@ -359,7 +359,7 @@ struct CellRay {
         const unsigned cell = POW2 ? (unsigned)(((((qz >> 2) << P.nc_log2) | (qy >> 2)) << P.nc_log2) | (qx >> 2))
                                    : (unsigned)(((qz >> 2) * nc + (qy >> 2)) * nc + (qx >> 2));
         const uint4 r = P.cells[cell];
-        const uint2 pw = P.pyr[cell];
+        const uint2 pw = reinterpret_cast<const uint2 *>(P.pyr)[2u * cell + (unsigned)(smy & 1)];  // rising: .x,.y
         cur_mask = (uint64_t)r.x | ((uint64_t)r.y << 32);
         d        = (int)((((dshift & 32) ? r.w : r.z) >> (dshift & 31)) & 0xffu);
         bit      = ((qz & 3) << 4) | ((qy & 3) << 2) | (qx & 3);  // off is a multiple of 4

@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void k_column_vtops(const uint4 *cells, int nc
     tops0[(size_t)tcz * nc + tcx] = (uint16_t)v;
 }
 
-__global__ __launch_bounds__(256) void k_voxel_pyramid(int nc, int offcy, PyramidLevels pyr, uint2 *out)
+__global__ __launch_bounds__(256) void k_voxel_pyramid(int nc, int offcy, PyramidLevels pyr, uint4 *out)
 {
     const int tcx = blockIdx.x * 64 + (threadIdx.x & 63);
     const int tcy = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -358,20 +358,31 @@ __global__ __launch_bounds__(256) void k_voxel_pyramid(int nc, int offcy, Pyrami
     if (tcx >= nc || tcy >= nc) return;
     int wl = tcy - offcy;
     wl += wl < 0 ? nc : 0;
-    unsigned e[4];
+    // Any level whose block top lies at or below the voxel gives a valid box; two choices are kept.
+    //   up[j]    the widest block: for rays that rise, which leave a block through its sides only
+    //   down[j]  the largest min(block width, 4 * height above the block's top): a wide block with
+    //            little room underneath ends a descending ray after a few voxels (measured on the bench
+    //            frame: 58 us against 62 us with the widest block; factors 2..4 alike, 1 worse)
+    unsigned up[4], down[4];
     for (int j = 0; j < 4; ++j) {
         const int v = 4 * wl + j;
-        unsigned best = 0;
+        unsigned widest = 0, best = 0;
+        int score = -1;
         for (int L = 0; L <= pyr.levels; ++L) {
             const int t = (int)pyr.tops[L][(size_t)(tcz >> L) * pyr.size[L] + (tcx >> L)];
-            if (t <= v) best = ((unsigned)(L + 1) << 12) | (unsigned)min(v - t, 4095); else break;  // tops grow with L
+            if (t > v) break;  // tops grow with L
+            const unsigned e = ((unsigned)(L + 1) << 12) | (unsigned)min(v - t, 4095);
+            const int sc = min(4 << L, 4 * (v - t + 1));
+            widest = e;
+            if (sc >= score) { score = sc; best = e; }
         }
-        e[j] = best;
+        up[j] = widest; down[j] = best;
     }
-    out[((size_t)tcz * nc + tcy) * nc + tcx] = make_uint2(e[0] | (e[1] << 16), e[2] | (e[3] << 16));
+    out[((size_t)tcz * nc + tcy) * nc + tcx] =
+        make_uint4(up[0] | (up[1] << 16), up[2] | (up[3] << 16), down[0] | (down[1] << 16), down[2] | (down[3] << 16));
 }
 
-hipError_t launch_build_voxel_pyramid(const uint4 *cells, int nc, int offcy, uint16_t *tops, uint2 *out, hipStream_t s)
+hipError_t launch_build_voxel_pyramid(const uint4 *cells, int nc, int offcy, uint16_t *tops, uint4 *out, hipStream_t s)
 {
     const dim3 blockdim(256);
     PyramidLevels pyr{};

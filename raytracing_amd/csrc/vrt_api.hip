@@ -127,7 +127,6 @@ int ensure_skip_structure(vrt_ctx *c, int offcy)
         c->pyr_offcy = -1;
     }
     if (c->pyr_offcy != offcy) {
-        HIP_TRY(vrt::launch_build_pyramid(c->d_cells, (int)c->n / 4, offcy, c->d_tops, c->stream));
         HIP_TRY(vrt::launch_build_voxel_pyramid(c->d_cells, (int)c->n / 4, offcy, c->d_tops, c->d_pyr, c->stream));
         c->pyr_offcy = offcy;
     }

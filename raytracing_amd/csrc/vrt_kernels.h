@@ -54,12 +54,7 @@ struct TraceParams {
     const void     *block;  // n^3 texels (u8 or u16), linear x fastest
     const uint16_t *dist;   // n^3 texels or nullptr (all zero)
     // skip structure: one 16-byte record per cell of 4^3 voxels (torus space, linear order)
-    //   .x,.y  non-empty cell: 64-bit occupancy mask, bit = (z&3)*16 + (y&3)*4 + (x&3);
-    //          empty cell: .x = L | layers << 8 -- the aligned block of 2^L x 2^L cell columns
-    //          (torus cell coordinates) around the cell has no non-empty cell in window layers
-    //          >= layers, and layers <= the cell's own layer; L = 0 if there is no such block.
-    //          Window layers are counted from the bottom of the loaded window, so this part is
-    //          rebuilt when the window's vertical offset changes.
+    //   .x,.y  64-bit occupancy mask, bit = (z&3)*16 + (y&3)*4 + (x&3); zero for an empty cell
     //   .z,.w  eight octant distances, byte o = sx | sy<<1 | sz<<2 (bit set = positive direction):
     //          side of the largest empty cube of cells that starts at the cell and extends into
     //          that octant; 0 = the cell is non-empty, cap 255
@@ -68,7 +63,8 @@ struct TraceParams {
     // column-top pyramid at voxel precision, two 64-bit words per cell (any cell, empty or not): for
     // each of the cell's four voxel levels j a 16-bit entry (L + 1) << 12 | drop -- the aligned block of
     // 2^L x 2^L cell columns around the cell holds no voxel at or above window level (4*layer + j) - drop
-    // (drop capped at 4095); 0 = not even the cell's own column qualifies.  .x,.y: the widest such block
+    // (drop capped at 4095); 0 = not even the cell's own column qualifies.  Window levels are counted from
+    // the bottom of the loaded window, so the pyramid is rebuilt when the window's vertical offset changes.  .x,.y: the widest such block
     // (read by rays that rise); .z,.w: the block the builder prefers for rays that descend.
     const uint4 *pyr;
     // per-frame tables (device memory, filled by launch_frame_tables with the kernels' own arithmetic;
@@ -100,9 +96,7 @@ hipError_t launch_terrain(void *block, int voxel_bytes, int n, int x0, int y0, i
                           int ex, int ey, int ez, hipStream_t s);
 // cells = nc^3 records; tmp = 11 * nc^3 bytes of scratch
 hipError_t launch_build_cells(const void *block, int voxel_bytes, int n, uint4 *cells, uint8_t *tmp, hipStream_t s);
-// tops: scratch of at least 2 * nc * nc uint16_t; offcy = rem_euclid(lower_y, n) / 4
-hipError_t launch_build_pyramid(uint4 *cells, int nc, int offcy, uint16_t *tops, hipStream_t s);
-// same scratch; pyr = nc^3 words
+// tops: scratch of at least 2 * nc * nc uint16_t; offcy = rem_euclid(lower_y, n) / 4; pyr = nc^3 records
 hipError_t launch_build_voxel_pyramid(const uint4 *cells, int nc, int offcy, uint16_t *tops, uint4 *pyr, hipStream_t s);
 hipError_t launch_frame_tables(float *ncx, float *ncy, float *sin2, uint32_t w, uint32_t h, float ncy_off,
                                const int32_t sin_base[3], uint32_t sin_len, hipStream_t s);

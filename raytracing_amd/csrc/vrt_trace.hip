@@ -182,7 +182,6 @@ VRT_DEV void traverse_skip(const TraceParams &P, float rox, float roy, float roz
     unsigned steps = 0, iters = 0;
     H.hit = 0; H.capped = 0; H.block_id = 0; H.k = 0; H.sk = 0;
     int      cur_cell = -1, d = 0;
-    unsigned info = 0;       // empty cells: column-top pyramid entry (level | layers << 8)
     uint64_t cur_mask = 0;   // non-empty cells: occupancy
     int qx = 0, qy = 0, qz = 0;  // texel of the anchor at the last cell lookup
     const bool pow2 = P.n_pow2_mask >= 0;  // wave uniform
@@ -197,7 +196,6 @@ VRT_DEV void traverse_skip(const TraceParams &P, float rox, float roy, float roz
         if (cell != cur_cell) {
             const uint4 r = P.cells[cell];
             cur_cell = cell;
-            info     = r.x;
             cur_mask = (uint64_t)r.x | ((uint64_t)r.y << 32);
             d        = (int)(((dhigh ? r.w : r.z) >> dshift) & 0xffu);
         }
@@ -213,22 +211,10 @@ VRT_DEV void traverse_skip(const TraceParams &P, float rox, float roy, float roz
         bool  unit = d == 0;
         int   fwx = wx, fwy = wy, fwz = wz;  // last anchor of the empty box on each axis
         if (!unit) {
-            const int lvl = (int)(info & 0xffu);
-            if (lvl > 0 && (1 << lvl) > d) {
-                // column-top pyramid: the aligned block of 2^lvl x 2^lvl cell columns around this
-                // one is empty from layer (info >> 8) up to the top of the window
-                const int m4 = (4 << lvl) - 1;
-                if (P.need_cap) locate();  // qx, qz may be stale after capped unit steps in an empty cell
-                // (a block as wide as the torus has no edge: the seam is not a boundary)
-                fwx = m4 >= n - 1 ? whix : min(wx + ((qx ^ ~smx) & m4), whix);
-                fwz = m4 >= n - 1 ? whiz : min(wz + ((qz ^ ~smz) & m4), whiz);
-                fwy = py ? whiy : min(~(int)((info >> 8) << 2), whiy);
-            } else {
-                const int r4 = (d - 1) << 2;
-                fwx = min((wx | 3) + r4, whix);
-                fwy = min((wy | 3) + r4, whiy);
-                fwz = min((wz | 3) + r4, whiz);
-            }
+            const int r4 = (d - 1) << 2;  // the octant cube (this form does not use the column-top pyramid)
+            fwx = min((wx | 3) + r4, whix);
+            fwy = min((wy | 3) + r4, whiy);
+            fwz = min((wz | 3) + r4, whiz);
             // the box may not carry the ray past the step cap (only with tiny caps)
             if (P.need_cap && steps + (unsigned)((fwx - wx) + (fwy - wy) + (fwz - wz) + 3) > P.max_steps) {
                 unit = true; fwx = wx; fwy = wy; fwz = wz;

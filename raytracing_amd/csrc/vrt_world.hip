@@ -7,8 +7,8 @@
 //   k_df_dir_pass   : one axis of the separable (min, max) octant distance transform over
 //                     cells (torus metric); x, y, z passes per direction octant.
 //   k_pack_dist     : the eight octant distances of a cell into its 16-byte record.
-//   k_column_tops, k_tops_reduce, k_pyramid_info : the column-top pyramid, stored in the
-//                     records of empty cells.
+//   k_column_vtops, k_tops_reduce, k_voxel_pyramid : the column-top pyramid at voxel precision,
+//                     one 16-byte record per cell next to the cell records.
 //   k_any_nonzero   : is the uploaded distance image all zero (as shipped)?
 #include "vrt_device.h"
 #include "vrt_kernels.h"
@@ -239,29 +239,13 @@ hipError_t launch_build_cells(const void *block, int voxel_bytes, int n, uint4 *
 }
 
 // ---------------------------------------------------------------------------
-// column-top pyramid
+// column-top pyramid at voxel precision (TraceParams::pyr)
 // ---------------------------------------------------------------------------
-// Layers are counted from the bottom of the loaded window: window layer wl of torus cell row
-// tcy is (tcy - offcy) mod nc, offcy = rem_euclid(lower_y, n) / 4.  tops[0][tcz][tcx] = number of
-// layers from the bottom that may hold a non-empty cell in that column (highest non-empty layer
-// + 1, 0 for an empty column); tops[L] = max over aligned 2^L x 2^L blocks of columns.
+// Levels are counted from the bottom of the loaded window: window layer wl of torus cell row tcy is
+// (tcy - offcy) mod nc, offcy = rem_euclid(lower_y, n) / 4, and window level v = 4*wl + (voxel row in the cell).
+// vtops[0][tcz][tcx] = window level just above the highest solid voxel of the 4x4 voxel columns of cell
+// column (tcx, tcz), 0 if they are empty; vtops[L] = max over aligned 2^L x 2^L blocks of cell columns.
 // A cell is non-empty iff its octant distances are zero.
-__global__ __launch_bounds__(256) void k_column_tops(const uint4 *cells, int nc, int offcy, uint16_t *tops0)
-{
-    const int tcx = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int tcz = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (tcx >= nc || tcz >= nc) return;
-    int v = 0;
-    for (int wl = nc - 1; wl >= 0; --wl) {
-        int tcy = wl + offcy;
-        tcy -= tcy >= nc ? nc : 0;
-        const uint4 *rec = cells + (((size_t)tcz * nc + tcy) * nc + tcx);
-        const unsigned dz = reinterpret_cast<const unsigned *>(rec)[2];
-        if ((dz & 0xffu) == 0) { v = wl + 1; break; }
-    }
-    tops0[(size_t)tcz * nc + tcx] = (uint16_t)v;
-}
-
 __global__ __launch_bounds__(256) void k_tops_reduce(const uint16_t *fine, int nfine, uint16_t *coarse, int ncoarse)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -277,59 +261,11 @@ __global__ __launch_bounds__(256) void k_tops_reduce(const uint16_t *fine, int n
 }
 
 struct PyramidLevels {
-    const uint16_t *tops[9];  // [1..8] used
+    const uint16_t *tops[9];  // [0..8]
     int             size[9];  // blocks per axis
     int             levels;   // highest level present
 };
 
-// For every EMPTY cell: the largest level L in 1..levels whose block top lies at or below the
-// cell's layer, written into the (otherwise unused) mask words: .x = L | layers << 8, .y = 0.
-__global__ __launch_bounds__(256) void k_pyramid_info(uint4 *cells, int nc, int offcy, PyramidLevels pyr)
-{
-    const int tcx = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int tcy = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int tcz = blockIdx.z;
-    if (tcx >= nc || tcy >= nc) return;
-    uint4 *rec = cells + (((size_t)tcz * nc + tcy) * nc + tcx);
-    const unsigned dz = reinterpret_cast<const unsigned *>(rec)[2];
-    if ((dz & 0xffu) == 0) return;  // non-empty: the words hold the occupancy mask
-    int wl = tcy - offcy;
-    wl += wl < 0 ? nc : 0;
-    unsigned best = 0;
-    for (int L = 1; L <= pyr.levels; ++L) {
-        const unsigned v = pyr.tops[L][(size_t)(tcz >> L) * pyr.size[L] + (tcx >> L)];
-        if ((int)v <= wl) best = (unsigned)L | (v << 8); else break;  // tops grow with L
-    }
-    *reinterpret_cast<uint2 *>(rec) = make_uint2(best, 0u);
-}
-
-// tops: scratch for all levels, at least 2 * nc * nc uint16_t
-hipError_t launch_build_pyramid(uint4 *cells, int nc, int offcy, uint16_t *tops, hipStream_t s)
-{
-    const dim3 blockdim(256);
-    uint16_t *level[9];
-    int       size[9];
-    level[0] = tops; size[0] = nc;
-    k_column_tops<<<dim3((nc + 63) / 64, (nc + 3) / 4), blockdim, 0, s>>>(cells, nc, offcy, level[0]);
-    PyramidLevels pyr{};
-    pyr.levels = 0;
-    for (int L = 1; L <= 8; ++L) {
-        // blocks are aligned in torus cell coordinates; a level must divide the grid evenly
-        if (nc % (1 << L) != 0) break;
-        size[L]  = nc >> L;
-        level[L] = level[L - 1] + (size_t)size[L - 1] * size[L - 1];
-        k_tops_reduce<<<dim3((size[L] + 63) / 64, (size[L] + 3) / 4), blockdim, 0, s>>>(level[L - 1], size[L - 1], level[L], size[L]);
-        pyr.tops[L] = level[L]; pyr.size[L] = size[L]; pyr.levels = L;
-    }
-    k_pyramid_info<<<dim3((nc + 63) / 64, (nc + 3) / 4, nc), blockdim, 0, s>>>(cells, nc, offcy, pyr);
-    return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------
-// column-top pyramid at voxel precision (TraceParams::pyr)
-// ---------------------------------------------------------------------------
-// vtops[0][tcz][tcx] = window level (voxels from the bottom of the loaded window) just above the highest
-// solid voxel of the 4x4 voxel columns of cell column (tcx, tcz), 0 if they are empty.
 __global__ __launch_bounds__(256) void k_column_vtops(const uint4 *cells, int nc, int offcy, uint16_t *tops0)
 {
     const int tcx = blockIdx.x * 64 + (threadIdx.x & 63);

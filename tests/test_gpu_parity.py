@@ -316,3 +316,17 @@ def test_repeated_frames_keep_their_pixels(scene160):
         for y0, y1 in [(0, 480), (0, 100), (0, 480), (37, 480), (37, 480), (37, 480), (37, 480), (37, 480)]:
             got = g.trace(cam, 640, 480, y0, y1, outputs=("bgra8", "voxel"))
             assert np.array_equal(got["bgra8"], want["bgra8"][y0:y1]) and np.array_equal(got["voxel"], want["voxel"][y0:y1])
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_ragged_frame_sizes(scene160, mode):
+    # frames that do not fill their 16x4 wave tiles or 16-row workgroups, each traced several times in a row
+    # (tables refilled per shape, dispatch order measured per shape)
+    p = scenes.pose_b()
+    cam = scenes.cam16(p)
+    world = O.World(scene160)
+    with core_for(scene160, mode) as g:
+        for w, h in [(100, 37), (17, 5), (1, 1), (65, 4), (3, 130), (333, 17)]:
+            want = O.trace(world, cam, w, h)
+            for i in range(5):
+                assert_planes_equal(g.trace(cam, w, h), want, f"{w}x{h} launch {i}")

@@ -8,7 +8,7 @@ import numpy as np
 import torch
 from raytracing_amd import GraphicsCore, Player, VOXEL_PACKED_U8, VOXEL_REF_U16U16, scenes
 
-which = [int(a) for a in sys.argv[1:]] or [2, 3, 4, 5]
+which = [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4, 5]
 
 
 def world(n, fmt, pose):
@@ -33,7 +33,15 @@ def steps_sum(g, cam, w, h):
 
 
 for c in which:
-    if c == 2:
+    if c == 1:
+        p = scenes.pose_b(); w, h, n = 640, 480, 160
+        g, build = world(n, VOXEL_REF_U16U16, p); cam = scenes.cam16(p)
+        fr = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+        ms = timed(g, lambda: g.trace_device(cam, w, h, 0, h, {"bgra8": fr.data_ptr()}), 50)
+        s = steps_sum(g, cam, w, h)
+        print(json.dumps({"config": 1, "desc": "640x480 over 160^3 u16+u16 (the reference's own window)", "kernel_ms": ms,
+                          "mrays_s": w*h/ms/1e3, "alg_GBs": (s*2 + w*h*(2+4))/ms/1e6, "build_s": build}))
+    elif c == 2:
         p = scenes.pose_b(); w, h, n = 1920, 1080, 256
         g, build = world(n, VOXEL_REF_U16U16, p); cam = scenes.cam16(p)
         fr = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")

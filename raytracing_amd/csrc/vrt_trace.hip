@@ -541,14 +541,7 @@ VRT_DEV bool pixel_of_thread(const TraceParams &P, unsigned by, unsigned &col, u
 {
     const unsigned tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const unsigned lh = P.tile_log2h, tw = 64u >> lh;
-    // Workgroups are dealt round-robin over the eight XCDs, each with an L2 of its own: workgroup x of a
-    // row goes where workgroup x + 8 goes.  Giving each XCD a contiguous eighth of every row (a vertical
-    // stripe of the frame) instead of every eighth tile lets its L2 hold one part of the cell records.
-    // (Stripe k takes the workgroups x = k, k + 8, ...: gridDim.x / 8 of them, one more for k < gridDim.x % 8.
-    // Measured on the bench frame: 1.3 MB instead of 4.2 MB fetched per frame, same kernel time.)
-    const unsigned k8 = blockIdx.x & 7u;
-    const unsigned bx = k8 * (gridDim.x >> 3) + min(k8, gridDim.x & 7u) + (blockIdx.x >> 3);
-    col = bx * tw + (lane & (tw - 1));
+    col = blockIdx.x * tw + (lane & (tw - 1));
     q   = ((by * 4 + wave) << lh) + (lane >> (6 - lh));
     if (col >= P.w || q >= P.rows.rows) return false;
     if (P.rows.strip_h == 0) {

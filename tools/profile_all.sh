@@ -9,5 +9,5 @@ timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun
 echo kt literal done
 bash tools/profile_pmc.sh --steps 8 || exit 1
 echo pmc done
-timeout -k 10 500 python tools/bench_configs.py 2 3 4 5 > gpurun_out/configs.json 2> gpurun_out/configs.err || exit 1
+timeout -k 10 500 python tools/bench_configs.py 1 2 3 4 5 > gpurun_out/configs.json 2> gpurun_out/configs.err || exit 1
 echo configs done

@@ -482,18 +482,20 @@ struct CellRay {
         }
     }
 
-    // outputs of a ray that has ended (live == false) after a successful begin()
-    VRT_DEV void finish(const TraceParams &P, float rox, float roy, float roz, float rdx, float rdy, float rdz,
-                        int lox, int loy, int loz, RayHit &H) const
+    // outputs of a ray that has ended (live == false) after a successful begin().  The direction and its
+    // reciprocal are rebuilt from their magnitudes and signs (negation is exact), so the caller's copies
+    // need not stay in registers across the loop.
+    VRT_DEV void finish(const TraceParams &P, float rox, float roy, float roz, int lox, int loy, int loz, RayHit &H) const
     {
+        const float rdx = smx ? -dnx : dnx, rdy = smy ? -dny : dny, rdz = smz ? -dnz : dnz;
         H.hit = hit ? 1 : 0; H.capped = 0; H.block_id = 0; H.k = 0; H.sk = 0;
         const int ax = (wx ^ smx) + lox, ay = (wy ^ smy) + loy, az = (wz ^ smz) + loz;
         if (hit) {
             H.k = k; H.sk = k == 0 ? (1 | smx) : (k == 1 ? (1 | smy) : (1 | smz));
             // t as the reference computes it, in the unmirrored frame (see traverse_skip)
             const int   pk = k == 0 ? ax - smx : (k == 1 ? ay - smy : az - smz);  // the entry plane: a + (s < 0)
-            const float th = ((float)pk - (k == 0 ? rox : (k == 1 ? roy : roz))) *
-                             (1.0f / (k == 0 ? rdx : (k == 1 ? rdy : rdz)));
+            const float ik = k == 0 ? (smx ? -inx : inx) : (k == 1 ? (smy ? -iny : iny) : (smz ? -inz : inz));  // 1 / rd_k
+            const float th = ((float)pk - (k == 0 ? rox : (k == 1 ? roy : roz))) * ik;
             H.t = th;
             H.hx = rox + rdx * th; H.hy = roy + rdy * th; H.hz = roz + rdz * th;
             H.block_id = load_block<T>(P, ax, ay, az);
@@ -515,7 +517,7 @@ VRT_DEV void traverse_cells(const TraceParams &P, float rox, float roy, float ro
         return;
     }
     while (ray.live) ray.trip(P);
-    ray.finish(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, H);
+    ray.finish(P, rox, roy, roz, lox, loy, loz, H);
 }
 
 // The traversal a launch runs is fixed on the host (one kernel instance per form keeps the uniform
@@ -732,7 +734,7 @@ VRT_DEV void finish_pixel(const TraceParams &P, unsigned gx, unsigned gy, size_t
     if (dx * dx + dy * dy <= 1) { r = 1.0f; g = 0.3f; b = 0.3f; a = 1.0f; }
 
     if (P.bgra8) {
-        const unsigned px = unorm8(b) | (unorm8(g) << 8) | (unorm8(r) << 16) | (unorm8(a) << 24);
+        const unsigned px = unorm8(b) | (unorm8(g) << 8) | (unorm8(r) << 16) | 0xff000000u;  // alpha is 1 on every path
         ((unsigned *)P.bgra8)[i] = px;
     }
     if (P.voxel) { P.voxel[3 * i] = H.vx; P.voxel[3 * i + 1] = H.vy; P.voxel[3 * i + 2] = H.vz; }

@@ -207,10 +207,18 @@ def main():
         kern_s = kern_ms / 1e3 / max(launches, 1)
         achieved = alg_bytes / kern_s / 1e9
         traffic = None
+        limiter = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get(core.last_kernel_name())
+                prof = json.load(open(tf))
+                traffic = prof.get(core.last_kernel_name())
+                valu = prof.get(core.last_kernel_name() + "_valu_instructions")
+                if valu:
+                    # what actually bounds the kernel: one wave64 VALU instruction occupies a SIMD for 4 cycles;
+                    # 256 CUs x 4 SIMDs at 2.4 GHz (instruction count from the committed PMC pass, time measured now)
+                    limiter = {"kind": "valu_issue", "valu_instructions_per_launch": valu,
+                               "frac_of_kernel_time": valu * 4 / 1024 / (kern_s * 2.4e9)}
             except Exception:
                 traffic = None
         line = {
@@ -238,6 +246,8 @@ def main():
                          "timed_launches": int(launches),
                          "kernel_mrays_s": W * H / kern_s / 1e6, "mean_steps_per_ray": sum_steps / (W * H)},
         }
+        if limiter:
+            line["roofline"]["limiter"] = limiter
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(core, cam, steps_np)
         print(json.dumps(line), flush=True)

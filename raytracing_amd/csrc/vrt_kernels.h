@@ -57,7 +57,7 @@ struct TraceParams {
     //   .x,.y  64-bit occupancy mask, bit = (z&3)*16 + (y&3)*4 + (x&3); zero for an empty cell
     //   .z,.w  eight octant distances, byte o = sx | sy<<1 | sz<<2 (bit set = positive direction):
     //          side of the largest empty cube of cells that starts at the cell and extends into
-    //          that octant; 0 = the cell is non-empty, cap 255
+    //          that octant; 0 = the cell is non-empty, cap 32
     const uint4 *cells;
     int32_t  nc;                // n / 4
     // column-top pyramid at voxel precision, two 64-bit words per cell (any cell, empty or not): for

@@ -2,7 +2,7 @@
 """Diagnostic: with VRT_SCHED_DEBUG=1 in the environment the library prints, before every skip launch,
 the start rows planned so far and the trip count per workgroup row the previous launch recorded."""
 import os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from raytracing_amd import GraphicsCore, VOXEL_PACKED_U8, TRACE_SKIP, scenes
 W, H, N = 1920, 1080, 1024

@@ -1,0 +1,69 @@
+//! UNVERIFIED (never compiled).  Declarations of include/vrt.h, one to one.
+#![allow(non_camel_case_types)]
+use std::os::raw::{c_char, c_int, c_void};
+
+#[repr(C)]
+pub struct VrtCtx {
+    _private: [u8; 0],
+}
+
+#[repr(C)]
+pub struct VrtConfig {
+    pub struct_size: u32,
+    pub device: i32,
+    pub grid_n: u32,
+    pub voxel_format: u32,
+    pub max_steps: u32,
+    pub trace_mode: u32,
+}
+
+#[repr(C)]
+pub struct VrtOutputs {
+    pub struct_size: u32,
+    pub memory: u32,
+    pub bgra8: *mut u8,
+    pub voxel: *mut i32,
+    pub face: *mut i32,
+    pub steps: *mut u32,
+    pub t: *mut f32,
+    pub hit_point: *mut f32,
+    pub rgba: *mut f32,
+}
+
+#[repr(C)]
+pub struct VrtSecondaryOutputs {
+    pub struct_size: u32,
+    pub memory: u32,
+    pub shadow: *mut u8,
+    pub ao: *mut u8,
+    pub sec_steps: *mut u32,
+}
+
+pub const VRT_OK: c_int = 0;
+pub const VRT_VOXEL_REF_U16U16: u32 = 0;
+pub const VRT_VOXEL_PACKED_U8: u32 = 1;
+pub const VRT_TRACE_AUTO: u32 = 0;
+pub const VRT_MEM_HOST: u32 = 0;
+pub const VRT_MEM_DEVICE: u32 = 1;
+
+extern "C" {
+    pub fn vrt_create(cfg: *const VrtConfig, out: *mut *mut VrtCtx) -> c_int;
+    pub fn vrt_destroy(ctx: *mut VrtCtx) -> c_int;
+    pub fn vrt_upload_world(ctx: *mut VrtCtx, block: *const c_void, dist: *const c_void, n: u32, memory: u32) -> c_int;
+    pub fn vrt_generate_chunk(ctx: *mut VrtCtx, cx: i32, cy: i32, cz: i32) -> c_int;
+    pub fn vrt_generate_window(ctx: *mut VrtCtx, wmin: *const i32) -> c_int;
+    pub fn vrt_reset_distance_field(ctx: *mut VrtCtx) -> c_int;
+    pub fn vrt_trace(ctx: *mut VrtCtx, cam_col_major: *const f32, w: u32, h: u32, y0: u32, y1: u32, out: *const VrtOutputs) -> c_int;
+    pub fn vrt_trace_secondary(ctx: *mut VrtCtx, cam_col_major: *const f32, w: u32, h: u32, y0: u32, y1: u32, out: *const VrtSecondaryOutputs) -> c_int;
+    pub fn vrt_trace_strips(ctx: *mut VrtCtx, cam_col_major: *const f32, w: u32, h: u32, strip_h: u32, part: u32, parts: u32, out: *const VrtOutputs) -> c_int;
+    pub fn vrt_strip_rows(h: u32, strip_h: u32, part: u32, parts: u32) -> u32;
+    pub fn vrt_sync(ctx: *mut VrtCtx) -> c_int;
+    pub fn vrt_download_world(ctx: *mut VrtCtx, block_out: *mut c_void, memory: u32) -> c_int;
+    pub fn vrt_kernel_time(ctx: *mut VrtCtx, total_ms: *mut f64, launches: *mut u64) -> c_int;
+    pub fn vrt_kernel_time_reset(ctx: *mut VrtCtx) -> c_int;
+    pub fn vrt_kernel_time_sampling(ctx: *mut VrtCtx, every_n: u32) -> c_int;
+    pub fn vrt_last_kernel_name(ctx: *mut VrtCtx) -> *const c_char;
+    pub fn vrt_stream(ctx: *mut VrtCtx) -> *mut c_void;
+    pub fn vrt_last_error() -> *const c_char;
+    pub fn vrt_version() -> *const c_char;
+}

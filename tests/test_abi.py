@@ -76,3 +76,11 @@ def test_no_device_is_a_loud_error_not_a_fallback():
     from raytracing_amd import GraphicsCore, VrtError
     with pytest.raises(VrtError):
         GraphicsCore()
+
+
+def test_rust_declarations_name_every_symbol():
+    # rust/src/vrt_sys.rs cannot be compiled here; at least its extern block must list the header's functions
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "rust", "src", "vrt_sys.rs")).read()
+    rust = sorted(set(re.findall(r"pub fn (vrt_[a-z_0-9]+)\s*\(", text)))
+    assert rust == declared_symbols()

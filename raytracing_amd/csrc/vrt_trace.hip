@@ -863,7 +863,23 @@ __global__ __launch_bounds__(256) void k_trace_secondary(const TraceParams P, ui
             const float soy = H.hy + (H.k == 1 ? nk : 0.0f) * 1e-3f;
             const float soz = H.hz + (H.k == 2 ? nk : 0.0f) * 1e-3f;
             const int face = 2 * H.k + (H.sk < 0 ? 1 : 0);
-            for (unsigned s = 0; s < 5; ++s) {
+            // The four ambient-occlusion rays are traced steepest first: within a pass the lanes of a
+            // wavefront then hold rays of similar elevation, which end after a similar number of trips
+            // (the directions are random per pixel; the sums written below do not depend on the order).
+            unsigned order = 0;  // four 4-bit ray indices, steepest first
+            {
+                unsigned hsh = pcg_hash(0x5EEDu ^ (row * P.w + col));
+                unsigned key[4];
+                for (unsigned j = 0; j < 4; ++j) {
+                    key[j] = ((hsh >> 8) << 3) | (j + 1u);  // u1 of ray j + 1 (24 bits) above its index
+                    hsh = pcg_hash(hsh); hsh = pcg_hash(hsh);
+                }
+                auto cswap = [&](int a, int b) { const unsigned lo = min(key[a], key[b]), hi = max(key[a], key[b]); key[a] = lo; key[b] = hi; };
+                cswap(0, 1); cswap(2, 3); cswap(0, 2); cswap(1, 3); cswap(1, 2);
+                order = (key[0] & 7u) | ((key[1] & 7u) << 4) | ((key[2] & 7u) << 8) | ((key[3] & 7u) << 12);
+            }
+            for (unsigned pass = 0; pass < 5; ++pass) {
+                const unsigned s = pass == 0 ? 0u : (order >> (4u * (pass - 1u))) & 7u;
                 float sdx, sdy, sdz;
                 secondary_dir(row * P.w + col, s, face, sdx, sdy, sdz);
                 RayHit S;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Long parity run (not part of pytest): many random poses over the procedural terrain, full frames,
 every output plane of the HIP skip kernel against the CPU oracle, bit for bit.
-usage: soak_parity.py [poses per world, default 40] [seed]   -> one summary line per world + total"""
+usage: soak_parity.py [poses per world, default 40] [seed] [default|odd]   -> one summary line per world + total"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -15,8 +15,12 @@ rng = np.random.default_rng(seed)
 PLANES = ("bgra8", "voxel", "face", "steps", "t", "hit_point", "rgba")
 total_px = total_bad = 0
 t_start = time.time()
-for n, fmt, dtype, w, h in [(160, VOXEL_REF_U16U16, np.uint16, 640, 480), (256, VOXEL_PACKED_U8, np.uint8, 960, 540),
-                            (1024, VOXEL_PACKED_U8, np.uint8, 1920, 1080)]:
+WORLDS = {"default": [(160, VOXEL_REF_U16U16, np.uint16, 640, 480), (256, VOXEL_PACKED_U8, np.uint8, 960, 540),
+                      (1024, VOXEL_PACKED_U8, np.uint8, 1920, 1080)],
+          # grids that are not powers of two (texel wrap by subtraction, fewer pyramid levels)
+          "odd": [(96, VOXEL_PACKED_U8, np.uint8, 640, 360), (480, VOXEL_REF_U16U16, np.uint16, 960, 540),
+                  (736, VOXEL_PACKED_U8, np.uint8, 1280, 720)]}
+for n, fmt, dtype, w, h in WORLDS[sys.argv[3] if len(sys.argv) > 3 else "default"]:
     centre = np.array([rng.uniform(-200, 200), 20.0, rng.uniform(-200, 200)], np.float32)
     wmin = scenes.window_min(centre, n)
     with GraphicsCore(grid_n=n, voxel_format=fmt, trace_mode=TRACE_SKIP) as g:

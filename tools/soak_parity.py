@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Long parity run (not part of pytest): many random poses over the procedural terrain, full frames,
 every output plane of the HIP skip kernel against the CPU oracle, bit for bit.
-usage: soak_parity.py [poses per world, default 40] [seed] [default|odd]   -> one summary line per world + total"""
+usage: soak_parity.py [poses per world, default 40] [seed] [default|odd|sparse]   -> one summary line per world + total"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -20,11 +20,22 @@ WORLDS = {"default": [(160, VOXEL_REF_U16U16, np.uint16, 640, 480), (256, VOXEL_
           # grids that are not powers of two (texel wrap by subtraction, fewer pyramid levels)
           "odd": [(96, VOXEL_PACKED_U8, np.uint8, 640, 360), (480, VOXEL_REF_U16U16, np.uint16, 960, 540),
                   (736, VOXEL_PACKED_U8, np.uint8, 1280, 720)]}
-for n, fmt, dtype, w, h in WORLDS[sys.argv[3] if len(sys.argv) > 3 else "default"]:
+kind = sys.argv[3] if len(sys.argv) > 3 else "default"
+WORLDS["sparse"] = [(64, VOXEL_PACKED_U8, np.uint8, 640, 360), (160, VOXEL_REF_U16U16, np.uint16, 640, 480),
+                    (256, VOXEL_PACKED_U8, np.uint8, 960, 540)]
+for n, fmt, dtype, w, h in WORLDS[kind]:
     centre = np.array([rng.uniform(-200, 200), 20.0, rng.uniform(-200, 200)], np.float32)
     wmin = scenes.window_min(centre, n)
     with GraphicsCore(grid_n=n, voxel_format=fmt, trace_mode=TRACE_SKIP) as g:
-        g.generate_window(wmin)
+        if kind == "sparse":
+            # not a height field: random voxels of two densities, floating slabs, a hollow shell
+            blk = (rng.random((n, n, n)) < (0.0005 if n > 128 else 0.01)).astype(dtype)
+            blk[:, n // 3, : n // 2] = 1
+            blk[n // 4: n // 2, 2 * n // 3, :] = 1
+            blk[n // 8: n // 4, :, n // 8] = 1
+            g.upload_world(blk)
+        else:
+            g.generate_window(wmin)
         world = O.World(g.download_world())
         base_chunk = scenes.chunk_of(centre)
         bad = px = 0

@@ -9,7 +9,9 @@ BGRA8 store) through libvrt.so.  The world (default procedural terrain over the 
 window around the camera) is generated on the GPU and indexed once, before timing, and
 stays resident in HBM.  With N > 1 every rank holds a replica of the world and traces a
 frame of its own camera pose (weak scaling); the BGRA8 framebuffers are gathered to rank
-0 over RCCL inside the timed region.
+0 over RCCL inside the timed region.  `--shard strips` is the other partition of the path: ONE
+frame dealt to the ranks in interleaved 16-row strips (strong scaling), gathered and put back
+in row order on rank 0 by the library's copy kernel.
 
 Prints ONE JSON line on rank 0.  `roofline.achieved` = algorithmic bytes per launch /
 mean HIP-event duration of the trace kernel, where algorithmic bytes are what the
@@ -31,9 +33,10 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-from raytracing_amd import GraphicsCore, Player, TRACE_AUTO, TRACE_LITERAL, TRACE_SKIP, VOXEL_PACKED_U8, scenes  # noqa: E402
+from raytracing_amd import GraphicsCore, Player, TRACE_AUTO, TRACE_LITERAL, TRACE_SKIP, VOXEL_PACKED_U8, scenes, sharding  # noqa: E402
 
 W, H, N_GRID = 1920, 1080, 1024
+STRIP_H = 16
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
 
 
@@ -67,6 +70,22 @@ def cpu_baseline(core, cam, steps_plane):
             "matches_gpu_steps": bool(ok)}
 
 
+def copy_bandwidth_gbs(nbytes=1 << 30, reps=10):
+    """Device-to-device copy rate of this GPU (bytes read + bytes written per second), the practical
+    ceiling beside the 8 TB/s data-sheet figure."""
+    a = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+    b = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+    for _ in range(3):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) / 1e3) / 1e9
+
+
 class stdout_to_stderr:
     """RCCL prints a version banner on stdout when its communicator comes up; this run's stdout is
     reserved for the one JSON line, so the file descriptor is pointed at stderr meanwhile."""
@@ -91,6 +110,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the RCCL gather path with a single rank as well (rehearsal of the N > 1 code on one GPU)")
+    ap.add_argument("--shard", choices=["poses", "strips"], default="poses",
+                    help="poses (the headline job): one frame of its own pose per rank, weak scaling; strips: ONE frame "
+                         "dealt to the ranks in interleaved 16-row strips, gathered and put back in row order on rank 0")
     ap.add_argument("--time-every", type=int, default=8,
                     help="bracket one frame in this many with HIP events (the events themselves cost stream time)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -125,7 +147,8 @@ def main():
     mode = {"auto": TRACE_AUTO, "skip": TRACE_SKIP, "literal": TRACE_LITERAL}[args.mode]
     core = GraphicsCore(width=W, height=H, device=local_rank, grid_n=N_GRID, voxel_format=VOXEL_PACKED_U8,
                         trace_mode=mode)
-    pose = rank_pose(rank, world)
+    strips = args.shard == "strips"
+    pose = rank_pose(0 if strips else rank, world)
     cam = scenes.cam16(pose)
     wmin = scenes.window_min(pose.get_position(), N_GRID)
     t0 = time.perf_counter()
@@ -143,6 +166,13 @@ def main():
     if multi and rank == 0:
         gathered = [[torch.zeros((H, W, 4), dtype=torch.uint8, device="cpu" if host else "cuda") for _ in range(world)]
                     for _ in range(2)]
+    if strips:
+        if host:
+            raise SystemExit("--shard strips gathers device buffers (RCCL); there is no gloo form of it")
+        pad_rows = sharding.max_strip_rows(H, STRIP_H, world)
+        packed = [torch.zeros((pad_rows, W, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+        parts_buf = [torch.zeros((world, pad_rows, W, 4), dtype=torch.uint8, device="cuda") if rank == 0 else None
+                     for _ in range(2)]
     pending = [None, None]
     torch.cuda.synchronize()
 
@@ -151,14 +181,32 @@ def main():
     core.sync()
     steps_np = steps_t.cpu().numpy().view(np.uint32)
     sum_steps = int(steps_np.astype(np.int64).sum())
-    alg_bytes = sum_steps * 1 + W * H * 4
+    launch_rays = W * H
+    if strips:                          # this rank's launch covers its own strips only
+        mine = sharding.strip_rows(H, STRIP_H, rank, world)
+        sum_steps = int(steps_np[mine].astype(np.int64).sum())
+        launch_rays = W * len(mine)
+    alg_bytes = sum_steps * 1 + launch_rays * 4
 
     counter = [0]
 
     def step():
         b = counter[0] & 1
         counter[0] += 1
-        if multi and not host:
+        if strips:
+            with torch.cuda.stream(stream):
+                if pending[b] is not None:
+                    pending[b].wait()
+                core.trace_strips_device(cam, W, H, STRIP_H, rank, world, {"bgra8": packed[b].data_ptr()})
+                if multi:
+                    pending[b] = dist.gather(packed[b], list(parts_buf[b].unbind(0)) if rank == 0 else None, dst=0,
+                                             async_op=True)
+                    if rank == 0:
+                        pending[b].wait()            # orders the copy below behind the gather on this stream
+                        pending[b] = None
+                        core.assemble_strips(parts_buf[b].data_ptr(), frames[b].data_ptr(), W * 4, H, STRIP_H, world,
+                                             pad_rows)
+        elif multi and not host:
             with torch.cuda.stream(stream):
                 if pending[b] is not None:
                     pending[b].wait()                # the trace below may overwrite frames[b] only after its gather
@@ -203,7 +251,7 @@ def main():
         dt, kern_max_s = float(t[0].item()), float(t[1].item())
 
     if rank == 0:
-        rays = W * H * args.steps * world
+        rays = W * H * args.steps * (1 if strips else world)
         kern_s = kern_ms / 1e3 / max(launches, 1)
         achieved = alg_bytes / kern_s / 1e9
         traffic = None
@@ -232,27 +280,37 @@ def main():
             # the same job without the framebuffer gather: every rank's frame / the slowest rank's kernel
             "value_without_gather": rays / args.steps / kern_max_s / 1e6,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strips else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "1920x1080 primary rays over 1024^3 u8 procedural terrain (pose B at y=40.3), "
-                                   "world replicated per GPU, one pose per GPU, BGRA8 gather to rank 0",
+                                   + ("world replicated per GPU, ONE frame dealt in interleaved 16-row strips, "
+                                      "BGRA8 gather + row reorder on rank 0" if strips else
+                                      "world replicated per GPU, one pose per GPU, BGRA8 gather to rank 0"),
                        "kernel": core.last_kernel_name(), "grid_n": N_GRID, "width": W, "height": H,
                        "world_build_s": round(build_s, 3)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_s * 1e3,
                          "timed_launches": int(launches),
-                         "kernel_mrays_s": W * H / kern_s / 1e6, "mean_steps_per_ray": sum_steps / (W * H)},
+                         "kernel_mrays_s": launch_rays / kern_s / 1e6, "mean_steps_per_ray": sum_steps / launch_rays},
         }
         if limiter:
             line["roofline"]["limiter"] = limiter
+        copy_gbs = copy_bandwidth_gbs()
+        line["roofline"]["measured_copy"] = {"GB/s": copy_gbs, "frac": achieved / copy_gbs}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(core, cam, steps_np)
         print(json.dumps(line), flush=True)
 
-    if multi and rank == 0 and not host:
+    if strips and multi and rank == 0:
+        # the reassembled frame is the frame traced in one piece
+        whole = torch.zeros_like(frames[0])
+        core.trace_device(cam, W, H, 0, H, {"bgra8": whole.data_ptr()})
+        core.sync()
+        assert torch.equal(frames[(counter[0] - 1) & 1], whole), "strips did not reassemble to the frame"
+    elif multi and rank == 0 and not host:
         # the last gathered frame of rank 0 is its own last frame
         assert torch.equal(gathered[(counter[0] - 1) & 1][0], frames[(counter[0] - 1) & 1]), "gather returned another frame"
     core.close()

@@ -132,6 +132,15 @@ int vrt_trace_strips(vrt_ctx *ctx, const float cam_col_major[16], uint32_t w, ui
                      uint32_t strip_h, uint32_t part, uint32_t parts, const vrt_outputs *out);
 uint32_t vrt_strip_rows(uint32_t h, uint32_t strip_h, uint32_t part, uint32_t parts);
 
+/* The step after the gather of a strip-sharded frame: `gathered` holds the packed planes of parts
+ * 0..parts-1 one after the other, part_stride_rows rows apart (at least the row count of the largest
+ * part; rows beyond a part's own are padding), each row row_bytes long (w * bytes per pixel of the
+ * plane); writes the h rows of `frame` in image order.  Both pointers are DEVICE memory and must not
+ * overlap; the copy is enqueued on the context's stream.  The reference renders on one device and
+ * has no counterpart (src/graphics/mod.rs:581-597). */
+int vrt_assemble_strips(vrt_ctx *ctx, const void *gathered, void *frame, uint32_t row_bytes, uint32_t h,
+                        uint32_t strip_h, uint32_t parts, uint32_t part_stride_rows);
+
 /* Wait for everything enqueued on the context's stream. */
 int vrt_sync(vrt_ctx *ctx);
 

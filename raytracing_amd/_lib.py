@@ -60,6 +60,8 @@ SYMBOLS = {
     "vrt_trace_strips": (C.c_int, [_CTX, _F, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                    C.POINTER(VrtOutputs)]),
     "vrt_strip_rows": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "vrt_assemble_strips": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                      C.c_uint32]),
     "vrt_sync": (C.c_int, [_CTX]),
     "vrt_download_world": (C.c_int, [_CTX, C.c_void_p, C.c_uint32]),
     "vrt_kernel_time": (C.c_int, [_CTX, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),

@@ -553,6 +553,25 @@ int vrt_trace_strips(vrt_ctx *c, const float cam[16], uint32_t w, uint32_t h, ui
     return do_trace(c, cam, w, h, rows, out);
 }
 
+int vrt_assemble_strips(vrt_ctx *c, const void *gathered, void *frame, uint32_t row_bytes, uint32_t h,
+                        uint32_t strip_h, uint32_t parts, uint32_t part_stride_rows)
+{
+    if (!c || !gathered || !frame) return fail(VRT_E_INVALID_ARG, "null argument");
+    if (strip_h == 0 || parts == 0 || row_bytes == 0 || h == 0 || h > 16384u)
+        return fail(VRT_E_INVALID_ARG, "bad strip partition or frame size");
+    uint32_t most = 0;
+    for (uint32_t part = 0; part < parts; ++part) {
+        const uint32_t rows = vrt_strip_rows(h, strip_h, part, parts);
+        if (rows > most) most = rows;
+    }
+    if (part_stride_rows < most)
+        return fail(VRT_E_INVALID_ARG, "part_stride_rows %u is less than the %u rows of the largest part", part_stride_rows, most);
+    if (gathered == frame) return fail(VRT_E_INVALID_ARG, "gathered and frame must not overlap");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(vrt::launch_assemble_strips(gathered, frame, row_bytes, h, strip_h, parts, part_stride_rows, c->stream));
+    return VRT_OK;
+}
+
 int vrt_sync(vrt_ctx *c)
 {
     if (!c) return fail(VRT_E_INVALID_ARG, "null argument");

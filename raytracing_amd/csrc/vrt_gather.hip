@@ -1,0 +1,47 @@
+// vrt_gather.hip -- puts gathered strip buffers back into frame order.
+//
+// After a frame has been traced in interleaved strips (vrt_trace_strips) and the packed planes of all
+// parts have been gathered into one buffer, every image row has to move once: row r of the frame is
+// packed row (s / parts) * strip_h + r % strip_h of part s % parts, s = r / strip_h.  One launch copies
+// all rows; each lane moves one 16-, 4- or 1-byte unit, consecutive lanes consecutive units of a row.
+// The reference renders on one device and has no such step (src/graphics/mod.rs:581-597).
+#include "vrt_kernels.h"
+
+namespace vrt {
+
+template <typename U>
+__global__ __launch_bounds__(256) void k_assemble_strips(const U *__restrict__ gathered, U *__restrict__ frame,
+                                                         uint32_t row_units, uint32_t strip_h, uint32_t parts,
+                                                         uint32_t part_stride_rows)
+{
+    const uint32_t r = blockIdx.y;
+    const uint32_t s = r / strip_h;
+    const uint32_t part = s % parts;
+    const uint32_t q = (s / parts) * strip_h + (r - s * strip_h);
+    const U *src = gathered + ((size_t)part * part_stride_rows + q) * row_units;
+    U *dst = frame + (size_t)r * row_units;
+    for (uint32_t u = blockIdx.x * 256u + threadIdx.x; u < row_units; u += gridDim.x * 256u)
+        dst[u] = src[u];
+}
+
+template <typename U>
+static hipError_t assemble(const void *gathered, void *frame, uint32_t row_units, uint32_t h, uint32_t strip_h,
+                           uint32_t parts, uint32_t part_stride_rows, hipStream_t s)
+{
+    uint32_t gx = (row_units + 255u) / 256u;
+    if (gx > 64u) gx = 64u;
+    hipLaunchKernelGGL(k_assemble_strips<U>, dim3(gx, h), dim3(256), 0, s, (const U *)gathered, (U *)frame, row_units,
+                       strip_h, parts, part_stride_rows);
+    return hipGetLastError();
+}
+
+hipError_t launch_assemble_strips(const void *gathered, void *frame, uint32_t row_bytes, uint32_t h,
+                                  uint32_t strip_h, uint32_t parts, uint32_t part_stride_rows, hipStream_t s)
+{
+    const uintptr_t align = (uintptr_t)gathered | (uintptr_t)frame | row_bytes;
+    if ((align & 15u) == 0) return assemble<uint4>(gathered, frame, row_bytes / 16u, h, strip_h, parts, part_stride_rows, s);
+    if ((align & 3u) == 0) return assemble<uint32_t>(gathered, frame, row_bytes / 4u, h, strip_h, parts, part_stride_rows, s);
+    return assemble<uint8_t>(gathered, frame, row_bytes, h, strip_h, parts, part_stride_rows, s);
+}
+
+}  // namespace vrt

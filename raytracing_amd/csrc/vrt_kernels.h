@@ -102,4 +102,8 @@ hipError_t launch_frame_tables(float *ncx, float *ncy, float *sin2, uint32_t w, 
                                const int32_t sin_base[3], uint32_t sin_len, hipStream_t s);
 hipError_t launch_any_nonzero_u16(const uint16_t *p, size_t count, uint32_t *flag, hipStream_t s);
 
+// Gathered strip buffers (parts x part_stride_rows packed rows of row_bytes each) -> frame of h rows.
+hipError_t launch_assemble_strips(const void *gathered, void *frame, uint32_t row_bytes, uint32_t h,
+                                  uint32_t strip_h, uint32_t parts, uint32_t part_stride_rows, hipStream_t s);
+
 }  // namespace vrt

@@ -183,6 +183,12 @@ class GraphicsCore:
         o = L.VrtOutputs(C.sizeof(L.VrtOutputs), L.MEM_DEVICE, *[ptrs.get(k) for k in _PLANES])
         L.check(L.lib().vrt_trace_strips(self._ctx, camp, w, h, strip_h, part, parts, C.byref(o)))
 
+    def assemble_strips(self, gathered, frame, row_bytes, h, strip_h, parts, part_stride_rows):
+        """Enqueue the copy of gathered strip buffers (device address; `parts` buffers, each
+        `part_stride_rows` packed rows of `row_bytes`) into the `h` rows of `frame` (device address)."""
+        L.check(L.lib().vrt_assemble_strips(self._ctx, gathered, frame, row_bytes, h, strip_h, parts,
+                                            part_stride_rows))
+
     def sync(self):
         L.check(L.lib().vrt_sync(self._ctx))
 

@@ -21,10 +21,16 @@ def max_strip_rows(h, strip_h, parts):
     return max(len(strip_rows(h, strip_h, p, parts)) for p in range(parts))
 
 
-def gather_frame(packed, h, strip_h, dst=0, group=None, out=None):
+def gather_frame(packed, h, strip_h, dst=0, group=None, out=None, core=None):
     """Gather every rank's packed rows (tensor [rows_r, ...]) to `dst` and return the full
     frame [h, ...] there (None elsewhere).  Ranks own different row counts when the strip
-    count is not a multiple of the world size, so buffers are padded to the largest."""
+    count is not a multiple of the world size, so buffers are padded to the largest.
+
+    With `core` (the GraphicsCore that traced `packed`, device tensors) the gather is ordered
+    behind the trace on the context's stream and the rows are put back by one launch of the
+    library's copy kernel (`vrt_assemble_strips`), enqueued on the same stream: call
+    `core.sync()` before reading the frame.  Without it (host tensors, the gloo rehearsal)
+    the rows are put back with tensor indexing."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     pad_rows = max_strip_rows(h, strip_h, world)
@@ -33,6 +39,24 @@ def gather_frame(packed, h, strip_h, dst=0, group=None, out=None):
         buf[:packed.shape[0]] = packed
     else:
         buf = packed
+    if core is not None:
+        if not packed.is_cuda:
+            raise ValueError("gather_frame(core=...) takes device tensors")
+        stream = torch.cuda.ExternalStream(core.stream(), device=packed.device)
+        with torch.cuda.stream(stream):
+            if rank != dst:
+                dist.gather(buf, None, dst=dst, group=group)
+                return None
+            parts = torch.empty((world,) + tuple(buf.shape), dtype=buf.dtype, device=buf.device)
+            dist.gather(buf, list(parts.unbind(0)), dst=dst, group=group)
+            frame = out if out is not None else packed.new_empty((h,) + tuple(packed.shape[1:]))
+            if not frame.is_contiguous() or frame.shape[0] != h:
+                raise ValueError("`out` must be a contiguous [h, ...] tensor")
+            row_bytes = frame[0].numel() * frame.element_size()
+            core.assemble_strips(parts.data_ptr(), frame.data_ptr(), row_bytes, h, strip_h, world, pad_rows)
+            parts.record_stream(stream)
+            frame.record_stream(stream)
+        return frame
     if rank == dst:
         parts = [torch.empty_like(buf) for _ in range(world)]
         dist.gather(buf, parts, dst=dst, group=group)

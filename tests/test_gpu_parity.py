@@ -180,6 +180,59 @@ def test_row_bands_and_strips_equal_the_full_frame(scene160):
         assert zero["steps"].shape == (0, 320)
 
 
+def test_gathered_strips_assemble_to_the_full_frame(scene160):
+    """Strips of all parts traced into one device buffer (what a gather delivers), put back in
+    image order by vrt_assemble_strips: equal to the frame traced in one piece.  h = 250 leaves
+    a short last strip and parts with different row counts."""
+    import torch
+    from raytracing_amd import sharding
+    cam = scenes.cam16(scenes.pose_b())
+    w, h, sh, parts = 320, 250, 16, 3
+    with core_for(scene160, TRACE_SKIP) as g:
+        full = g.trace(cam, w, h, outputs=("bgra8", "steps"))
+        pad = sharding.max_strip_rows(h, sh, parts)
+        gathered = {"bgra8": torch.full((parts, pad, w, 4), 0xEE, dtype=torch.uint8, device="cuda"),
+                    "steps": torch.full((parts, pad, w), -7, dtype=torch.int32, device="cuda")}
+        frames = {"bgra8": torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda"),
+                  "steps": torch.zeros((h, w), dtype=torch.int32, device="cuda")}
+        torch.cuda.synchronize()
+        for part in range(parts):
+            g.trace_strips_device(cam, w, h, sh, part, parts, {k: v[part].data_ptr() for k, v in gathered.items()})
+        g.assemble_strips(gathered["bgra8"].data_ptr(), frames["bgra8"].data_ptr(), w * 4, h, sh, parts, pad)
+        g.assemble_strips(gathered["steps"].data_ptr(), frames["steps"].data_ptr(), w * 4, h, sh, parts, pad)
+        g.sync()
+        assert np.array_equal(frames["bgra8"].cpu().numpy(), full["bgra8"])
+        assert np.array_equal(frames["steps"].cpu().numpy().view(np.uint32), full["steps"])
+
+
+@pytest.mark.parametrize("row_bytes,h,sh,parts,extra", [(1280, 64, 16, 2, 0), (1288, 70, 8, 3, 2), (321, 33, 4, 5, 1),
+                                                       (7680, 1080, 16, 8, 0), (16, 5, 16, 4, 0)])
+def test_assemble_strips_moves_every_row_once(row_bytes, h, sh, parts, extra):
+    """Random bytes through the 16-, 4- and 1-byte forms of the copy against the row map written out in
+    numpy; `extra` rows of slack between the parts' buffers."""
+    import torch
+    from raytracing_amd import sharding
+    rng = np.random.default_rng(row_bytes + h)
+    pad = sharding.max_strip_rows(h, sh, parts) + extra
+    src = rng.integers(0, 256, (parts, pad, row_bytes), dtype=np.uint8)
+    want = np.zeros((h, row_bytes), np.uint8)
+    for part in range(parts):
+        rows = sharding.strip_rows(h, sh, part, parts)
+        want[rows] = src[part, :len(rows)]
+    with GraphicsCore(width=16, height=16, grid_n=8, voxel_format=VOXEL_PACKED_U8) as g:
+        d_src = torch.from_numpy(src).cuda()
+        d_dst = torch.zeros((h, row_bytes), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        g.assemble_strips(d_src.data_ptr(), d_dst.data_ptr(), row_bytes, h, sh, parts, pad)
+        g.sync()
+        assert np.array_equal(d_dst.cpu().numpy(), want)
+        with pytest.raises(VrtError) as e:        # a stride shorter than the largest part
+            g.assemble_strips(d_src.data_ptr(), d_dst.data_ptr(), row_bytes, h, sh, parts, pad - extra - 1)
+        assert e.value.code == -1
+        with pytest.raises(VrtError):
+            g.assemble_strips(d_src.data_ptr(), d_dst.data_ptr(), row_bytes, h, 0, parts, pad)
+
+
 def test_device_resident_outputs_match_host_outputs(scene160):
     import torch
     cam = scenes.cam16(scenes.pose_b())

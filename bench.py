@@ -167,8 +167,6 @@ def main():
         gathered = [[torch.zeros((H, W, 4), dtype=torch.uint8, device="cpu" if host else "cuda") for _ in range(world)]
                     for _ in range(2)]
     if strips:
-        if host:
-            raise SystemExit("--shard strips gathers device buffers (RCCL); there is no gloo form of it")
         pad_rows = sharding.max_strip_rows(H, STRIP_H, world)
         packed = [torch.zeros((pad_rows, W, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
         parts_buf = [torch.zeros((world, pad_rows, W, 4), dtype=torch.uint8, device="cuda") if rank == 0 else None
@@ -193,7 +191,16 @@ def main():
     def step():
         b = counter[0] & 1
         counter[0] += 1
-        if strips:
+        if strips and host:
+            core.trace_strips_device(cam, W, H, STRIP_H, rank, world, {"bgra8": packed[b].data_ptr()})
+            core.sync()
+            cpu_parts = [torch.empty((pad_rows, W, 4), dtype=torch.uint8) for _ in range(world)] if rank == 0 else None
+            dist.gather(packed[b].cpu(), cpu_parts, dst=0)
+            if rank == 0:
+                parts_buf[b].copy_(torch.stack(cpu_parts))
+                torch.cuda.synchronize()
+                core.assemble_strips(parts_buf[b].data_ptr(), frames[b].data_ptr(), W * 4, H, STRIP_H, world, pad_rows)
+        elif strips:
             with torch.cuda.stream(stream):
                 if pending[b] is not None:
                     pending[b].wait()
@@ -257,7 +264,7 @@ def main():
         traffic = None
         limiter = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf):
+        if os.path.exists(tf) and not strips:   # the committed counters describe whole-frame launches
             try:
                 prof = json.load(open(tf))
                 traffic = prof.get(core.last_kernel_name())

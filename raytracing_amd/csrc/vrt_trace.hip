@@ -108,6 +108,76 @@ VRT_DEV void traverse_literal(const TraceParams &P, float rox, float roy, float 
     if (!H.hit) { H.t = -1.0f; H.hx = H.hy = H.hz = 0.0f; }
 }
 
+// The literal loop for a ray whose direction has a zero component, which the box algebra below cannot
+// take as it is: 1 / 0 puts infinities and NaNs into the plane parameters (raytrace.glsl:27,45).  What
+// the reference's arithmetic does with them, per zero axis k (s01 = 0, s11 = -1, cp_k = anchor_k):
+//   t_k = (cp_k - ro_k) * (+-inf) is -inf, +inf or NaN (cp_k == ro_k).
+//   +inf, or NaN on y or z, never wins argmin (util.glsl:28-42) and the position on axis k stays ro_k:
+//        the axis is "passive", the anchor keeps its coordinate and the ray is an ordinary ray in the
+//        other axes.
+//   -inf, or NaN on x, wins: the position becomes NaN, line :50 sets anchor_k = f2i(NaN) - 1 = -1, and
+//        the next t_k is taken from there.  Either the axis is passive then, or the same voxel is tested
+//        again and again until the step cap.
+// So the loop runs literally, and ends early in two provable ways: when an iteration leaves cp as it
+// was, every later iteration repeats it and the ray ends at the step cap; when every zero axis has
+// become passive (and the others are regular), the rest of the ray is handed to the box traversal,
+// frozen on the zero axes (CellRay::resume).  Returns true on such a hand-over, with the anchor and the
+// iterations made so far; false when the ray ended here and H holds its result.
+template <typename T>
+VRT_DEV bool traverse_degenerate(const TraceParams &P, float rox, float roy, float roz, float rdx, float rdy,
+                                 float rdz, int lox, int loy, int loz, int upx, int upy, int upz, RayHit &H,
+                                 int &ax, int &ay, int &az, unsigned &steps)
+{
+    const float invx = 1.0f / rdx, invy = 1.0f / rdy, invz = 1.0f / rdz;          // :27
+    const int   s01x = rdx > 0.0f ? 1 : 0, s01y = rdy > 0.0f ? 1 : 0, s01z = rdz > 0.0f ? 1 : 0;  // :29
+    const int   s11x = 2 * s01x - 1, s11y = 2 * s01y - 1, s11z = 2 * s01z - 1;     // :30
+    const float big = 0x1.0p100f;
+    const bool  zx = rdx == 0.0f, zy = rdy == 0.0f, zz = rdz == 0.0f;
+    // every axis either zero or fit for the box algebra, and at least one of the latter
+    const bool  can_resume = (zx || fabsf(invx) < big) && (zy || fabsf(invy) < big) && (zz || fabsf(invz) < big) &&
+                             !(zx && zy && zz);
+    ax = f2i(floorf(rox)); ay = f2i(floorf(roy)); az = f2i(floorf(roz));           // :32
+    int cpx = wadd(ax, s01x), cpy = wadd(ay, s01y), cpz = wadd(az, s01z);          // :35, zero distance
+    steps = 0;
+    H.hit = 0; H.capped = 0; H.block_id = 0; H.k = 0; H.sk = 0;
+    for (;;) {
+        if (can_resume && steps <= 8u) {
+            const float fx = ((float)cpx - rox) * invx, fy = ((float)cpy - roy) * invy, fz = ((float)cpz - roz) * invz;
+            const float inf = __builtin_inff();
+            if ((!zx || fx == inf) && (!zy || !(fy < inf)) && (!zz || !(fz < inf))) return true;
+        }
+        if (!(lox < cpx && loy < cpy && loz < cpz && cpx < upx && cpy < upy && cpz < upz)) break;  // :43
+        if (steps >= P.max_steps) { H.capped = 1; break; }
+        ++steps;                                                                    // :44
+        const float tx = ((float)cpx - rox) * invx;                                 // :45
+        const float ty = ((float)cpy - roy) * invy;
+        const float tz = ((float)cpz - roz) * invz;
+        const int   k  = argmin3(tx, ty, tz);                                       // :46
+        const float tk = k == 0 ? tx : (k == 1 ? ty : tz);
+        const float px = rox + rdx * tk, py = roy + rdy * tk, pz = roz + rdz * tk;
+        const float pk  = k == 0 ? px : (k == 1 ? py : pz);
+        const int   s01 = k == 0 ? s01x : (k == 1 ? s01y : s01z);
+        const int   ak  = wadd(wsub(f2i(rintf(pk)), 1), s01);                       // :50 (:49 keeps the anchor, see traverse_literal)
+        if (k == 0) ax = ak; else if (k == 1) ay = ak; else az = ak;
+        const unsigned b = load_block<T>(P, ax, ay, az);                            // :52
+        if (b > 0) {                                                                // :53-60
+            H.hit = 1; H.block_id = b; H.k = k; H.sk = k == 0 ? s11x : (k == 1 ? s11y : s11z);
+            H.t = tk; H.hx = px; H.hy = py; H.hz = pz;
+            break;
+        }
+        const int ncx = wadd(ax, s01x), ncy = wadd(ay, s01y), ncz = wadd(az, s01z);  // :67
+        if (ncx == cpx && ncy == cpy && ncz == cpz) {
+            // nothing changed and the voxel is air: the loop repeats this iteration up to the cap
+            steps = P.max_steps; H.capped = 1;
+            break;
+        }
+        cpx = ncx; cpy = ncy; cpz = ncz;
+    }
+    H.vx = ax; H.vy = ay; H.vz = az; H.steps = steps; H.iters = steps; H.work = 0;
+    if (!H.hit) { H.t = -1.0f; H.hx = H.hy = H.hz = 0.0f; }
+    return false;
+}
+
 // ---------------------------------------------------------------------------
 // exact empty-space skipping
 // ---------------------------------------------------------------------------
@@ -355,42 +425,47 @@ struct CellRay {
     // pyramid entry of the current voxel's level (0: none); `bit` carries the level in bits 2..3
     VRT_DEV unsigned entry() const { return (((bit & 8) ? pyr_hi : pyr_lo) >> ((bit & 4) << 2)) & 0xffffu; }
 
-    // false: the direction has a zero or non-finite component and the ray takes the literal loop
-    VRT_DEV bool begin(const TraceParams &P, float rox, float roy, float roz, float rdx, float rdy, float rdz,
-                       int lox, int loy, int loz)
+    // Starts (or takes over) a ray at anchor (ax, ay, az) after `steps` iterations of the reference's loop:
+    // (floor(ro), 0) for an ordinary ray; the state traverse_degenerate hands over for a ray with zero
+    // direction components, all of them passive.  Such an axis is frozen by its constants alone, trip()
+    // is the same code: origin -2^30 with an infinite reciprocal puts every plane parameter of the axis
+    // at +inf (never the argmin), the exit position -2^30 floors far below the anchor, which the clamp
+    // to the box then keeps, and the margin test never fires.  The stored magnitude carries the sign
+    // that lets finish() rebuild the direction bit for bit (sm = -1: rd = -dn).
+    // (MAY_FREEZE = false: the caller knows that no component is zero)
+    template <bool MAY_FREEZE>
+    VRT_DEV void begin(const TraceParams &P, float rox, float roy, float roz, float rdx, float rdy, float rdz,
+                       int lox, int loy, int loz, int ax, int ay, int az, unsigned steps)
     {
-        const float invx = 1.0f / rdx, invy = 1.0f / rdy, invz = 1.0f / rdz;
-        const float big = 0x1.0p100f;
-        const bool regular = (rdx != 0.0f) && (rdy != 0.0f) && (rdz != 0.0f) && (fabsf(invx) < big) &&
-                             (fabsf(invy) < big) && (fabsf(invz) < big);
-        live = false; hit = false; k = 0; d = 0; pyr_lo = pyr_hi = 0; cur_mask = 0; work = 0; iters = 0; bit = 0;
-        qx = qy = qz = 0;
-        if (!regular) return false;
-        const int n = P.n;
-        const bool px = rdx > 0.0f, py = rdy > 0.0f, pz = rdz > 0.0f;
+        const int   n = P.n;
+        const bool  zx = MAY_FREEZE && rdx == 0.0f, zy = MAY_FREEZE && rdy == 0.0f, zz = MAY_FREEZE && rdz == 0.0f;
+        const bool  px = rdx > 0.0f, py = rdy > 0.0f, pz = rdz > 0.0f;
+        const float far = -0x1.0p30f, never = 0x1.0p40f;
+        hit = false; k = 0; work = 0; iters = 0;
         smx = px ? 0 : -1; smy = py ? 0 : -1; smz = pz ? 0 : -1;
-        rnx = px ? rox : -rox; rny = py ? roy : -roy; rnz = pz ? roz : -roz;
-        dnx = fabsf(rdx); dny = fabsf(rdy); dnz = fabsf(rdz);
-        inx = fabsf(invx); iny = fabsf(invy); inz = fabsf(invz);
+        rnx = zx ? far : (px ? rox : -rox); rny = zy ? far : (py ? roy : -roy); rnz = zz ? far : (pz ? roz : -roz);
+        dnx = zx ? -rdx : fabsf(rdx); dny = zy ? -rdy : fabsf(rdy); dnz = zz ? -rdz : fabsf(rdz);
+        inx = fabsf(1.0f / rdx); iny = fabsf(1.0f / rdy); inz = fabsf(1.0f / rdz);  // +inf on a frozen axis
         lnx = px ? lox : -lox; lny = py ? loy : -loy; lnz = pz ? loz : -loz;
         const int oct = (px ? 1 : 0) | (py ? 2 : 0) | (pz ? 4 : 0);
         dshift = 8 * (oct & 3) + (oct >= 4 ? 32 : 0);
         // margin of the exit-point test, as 0.5 - 2^-20 * (|pos| + |origin| + 1) = thr0 - 2^-20 * |pos|
-        thr0x = 0.5f - 0x1.0p-20f * (fabsf(rnx) + 1.0f);
-        thr0y = 0.5f - 0x1.0p-20f * (fabsf(rny) + 1.0f);
-        thr0z = 0.5f - 0x1.0p-20f * (fabsf(rnz) + 1.0f);
-        wx = (f2i_small(floorf(rox)) - lox) ^ smx;
-        wy = (f2i_small(floorf(roy)) - loy) ^ smy;
-        wz = (f2i_small(floorf(roz)) - loz) ^ smz;
+        thr0x = zx ? never : 0.5f - 0x1.0p-20f * (fabsf(rnx) + 1.0f);
+        thr0y = zy ? never : 0.5f - 0x1.0p-20f * (fabsf(rny) + 1.0f);
+        thr0z = zz ? never : 0.5f - 0x1.0p-20f * (fabsf(rnz) + 1.0f);
+        wx = wsub(ax, lox) ^ smx; wy = wsub(ay, loy) ^ smy; wz = wsub(az, loz) ^ smz;
         // every step moves one axis by +1 in the mirrored frame: the step count is the distance from here
-        w0 = wx + wy + wz;
+        w0 = wx + wy + wz - (int)steps;
         const unsigned span = (unsigned)(n - 3);
         // loop test lower < a + s01 < upper  <=>  wlo <= w <= wlo + n - 3, wlo = 0 (s > 0) or 1 - n (s < 0)
         live = (unsigned)(wx - (smx & (1 - n))) <= span && (unsigned)(wy - (smy & (1 - n))) <= span &&
                (unsigned)(wz - (smz & (1 - n))) <= span;
-        if (live) locate(P);  // the start voxel's cell (the voxel itself is never tested)
-        return true;
+        d = 0; pyr_lo = pyr_hi = 0; cur_mask = 0; bit = 0; qx = qy = qz = 0;
+        if (live) locate(P);  // the anchor's cell (the start voxel itself is never tested)
     }
+
+    // a ray that ended elsewhere: the loop has nothing to do for this lane
+    VRT_DEV void idle() { live = false; hit = false; work = 0; iters = 0; }
 
     // One trip for the lanes with a live ray.  On entry the current voxel has been tested (or is the
     // start voxel) and lies inside the loaded area.
@@ -507,17 +582,42 @@ struct CellRay {
     }
 };
 
+// The box algebra needs non-zero directions and finite plane parameters.
+VRT_DEV bool ray_is_regular(float rdx, float rdy, float rdz)
+{
+    const float big = 0x1.0p100f;
+    return (rdx != 0.0f) && (rdy != 0.0f) && (rdz != 0.0f) && (fabsf(1.0f / rdx) < big) && (fabsf(1.0f / rdy) < big) &&
+           (fabsf(1.0f / rdz) < big);
+}
+
+// a ray for which ray_is_regular holds
+template <typename T, bool POW2>
+VRT_DEV void traverse_cells_regular(const TraceParams &P, float rox, float roy, float roz, float rdx, float rdy,
+                                    float rdz, int lox, int loy, int loz, RayHit &H)
+{
+    CellRay<T, POW2> ray;
+    ray.template begin<false>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, f2i_small(floorf(rox)),
+                              f2i_small(floorf(roy)), f2i_small(floorf(roz)), 0u);
+    while (ray.live) ray.trip(P);
+    ray.finish(P, rox, roy, roz, lox, loy, loz, H);
+}
+
+// any ray: one that is not regular starts in the literal loop (NaN / inf semantics of the reference), which
+// hands it back when the rest of it is an ordinary ray in the other axes
 template <typename T, bool POW2>
 VRT_DEV void traverse_cells(const TraceParams &P, float rox, float roy, float roz, float rdx, float rdy,
                             float rdz, int lox, int loy, int loz, int upx, int upy, int upz, RayHit &H)
 {
     CellRay<T, POW2> ray;
-    if (!ray.begin(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz)) {
-        traverse_literal<T, false>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
-        return;
-    }
+    int      ax = f2i_small(floorf(rox)), ay = f2i_small(floorf(roy)), az = f2i_small(floorf(roz));
+    unsigned steps = 0;
+    bool     boxed = true;
+    if (!ray_is_regular(rdx, rdy, rdz))
+        boxed = traverse_degenerate<T>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H, ax, ay, az, steps);
+    if (boxed) ray.template begin<true>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, ax, ay, az, steps);
+    else ray.idle();
     while (ray.live) ray.trip(P);
-    ray.finish(P, rox, roy, roz, lox, loy, loz, H);
+    if (boxed) ray.finish(P, rox, roy, roz, lox, loy, loz, H);
 }
 
 // The traversal a launch runs is fixed on the host (one kernel instance per form keeps the uniform
@@ -765,6 +865,25 @@ __global__ __launch_bounds__(256) void k_trace_literal(const TraceParams P)
     finish_pixel(P, gx, gy, (size_t)q * P.w + col, H);
 }
 
+// A pixel whose ray has a zero direction component (a pixel or two in one frame out of twenty; the middle
+// column with the reference's start orientation), from ray generation to the stores.  A function of its own,
+// called after the loop of the other lanes, with the launch parameters read through a pointer to the kernel
+// argument segment (TraceParams is the kernel's only argument): this seldom used code then has its own
+// registers and costs the loop of the ordinary rays none.  Returns the trips of the two-phase loop.
+template <typename T, int FORM>
+__device__ __attribute__((noinline)) unsigned degenerate_pixel(const TraceParams *params, unsigned gx, unsigned gy, unsigned q)
+{
+    const TraceParams &P = *params;
+    float rdx, rdy, rdz;
+    raygen(P, gx, gy, rdx, rdy, rdz);
+    const float rox = P.m[12], roy = P.m[13], roz = P.m[14];
+    const int lox = P.lo[0], loy = P.lo[1], loz = P.lo[2], upx = P.up[0], upy = P.up[1], upz = P.up[2];
+    RayHit H;
+    traverse_auto<T, FORM>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
+    finish_pixel(P, gx, gy, (size_t)q * P.w + gx, H);
+    return H.work;
+}
+
 // (eight wavefronts per SIMD, i.e. at most 64 VGPRs: measured 1.8 % faster than the 65 the compiler takes unasked)
 template <typename T, int FORM>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_trace_skip(const TraceParams P)
@@ -781,10 +900,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         const float rox = P.m[12], roy = P.m[13], roz = P.m[14];
         // loaded area (raytrace.glsl:19-24), evaluated once per frame on the host
         const int lox = P.lo[0], loy = P.lo[1], loz = P.lo[2], upx = P.up[0], upy = P.up[1], upz = P.up[2];
-        RayHit H;
-        traverse_auto<T, FORM>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
-        work = H.work;
-        finish_pixel(P, gx, gy, (size_t)q * P.w + col, H);
+        const bool regular = FORM == FORM_CAPPED || ray_is_regular(rdx, rdy, rdz);
+        if (regular) {
+            RayHit H;
+            if (FORM == FORM_CAPPED) traverse_skip<T>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
+            else traverse_cells_regular<T, FORM == FORM_POW2>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, H);
+            work = H.work;
+            finish_pixel(P, gx, gy, (size_t)q * P.w + col, H);
+        }
+        if (!regular)  // (the builtin is only valid in the kernel itself; TraceParams sits at offset 0 of the segment)
+            work = degenerate_pixel<T, FORM>((const TraceParams *)__builtin_amdgcn_kernarg_segment_ptr(), gx, gy, q);
 #ifdef VRT_DIAG_CLOCK
         // diagnostic build: start tick (100 MHz) in the face plane, duration in the steps plane
         const long long d1 = wall_clock64();

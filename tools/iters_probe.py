@@ -6,9 +6,11 @@ diagnostic library build, whose steps plane carries the kernel's own loop count:
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from raytracing_amd import GraphicsCore, VOXEL_PACKED_U8, TRACE_SKIP, scenes
+from raytracing_amd import GraphicsCore, Player, VOXEL_PACKED_U8, TRACE_SKIP, scenes
 W, H, N = 1920, 1080, 1024
 p = scenes.pose_headline()
+if len(sys.argv) > 1:   # another pitch from the same position
+    p = Player.at(p.get_position(), scenes.POSE_B_YAW, float(sys.argv[1]))
 with GraphicsCore(grid_n=N, voxel_format=VOXEL_PACKED_U8, trace_mode=TRACE_SKIP) as g:
     g.generate_window(scenes.window_min(p.get_position(), N)); g.reset_distance_field()
     out = g.trace(scenes.cam16(p), W, H, outputs=("steps", "face"))
@@ -24,3 +26,6 @@ t = it[:H//8*8, :W//8*8].reshape(H//8, 8, W//8, 8)
 mx = t.max(axis=(1, 3)); mn = t.mean(axis=(1, 3))
 print("wave-level: sum of max", mx.sum() * 64, "sum of lanes", it.sum(), "lane efficiency", it.sum() / (mx.sum() * 64))
 print("histogram of iters:", np.histogram(it, bins=[0, 2, 4, 8, 16, 32, 64, 128, 256, 100000])[0])
+worst = np.argwhere(it >= it.max() * 0.9)
+print("pixels within 10 % of the max:", len(worst), "rows", worst[:, 0].min(), worst[:, 0].max(), "cols", worst[:, 1].min(), worst[:, 1].max())
+print("reference steps there:", out["steps_ref"][it >= it.max() * 0.9][:8] if "steps_ref" in out else "")

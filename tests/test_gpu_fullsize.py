@@ -74,6 +74,24 @@ def test_headline_frame_skip_equals_literal_and_oracle(world1024):
     assert np.array_equal(np.concatenate([a["bgra8"], b["bgra8"]]), skip["bgra8"])
 
 
+def test_full_size_frame_with_one_zero_component_ray(world1024):
+    """The bench position looking up (pitch 1.2): pixel (row 697, column 135) gets rd.z == 0 exactly.
+    Its ray runs the reference's infinity arithmetic (the anchor jumps to z = -1) and then walks some
+    800 voxels as an ordinary ray in x and y; the kernel hands that part to its box traversal."""
+    g, block, p = world1024
+    W, H = 1920, 1080
+    cam = scenes.cam16(Player.at(p.get_position(), scenes.POSE_B_YAW, 1.2))
+    got = g.trace(cam, W, H)
+    want = O.trace(O.World(block), cam, W, H, 688, 704)
+    for k in PLANES:
+        assert same(got[k][688:704], want[k]), k
+    assert got["voxel"][697, 135, 2] == -1 and got["steps"][697, 135] > 500
+    start = np.floor(p.get_position()).astype(np.int64)
+    l1 = np.abs(got["voxel"].astype(np.int64) - start).sum(axis=2)
+    odd = l1 != got["steps"].astype(np.int64)          # only that ray breaks the L1 property
+    assert odd.sum() == 1 and odd[697, 135]
+
+
 def test_headline_world_from_other_chunks(world1024):
     # the camera leaves the chunk the world was generated for: the window (and its vertical
     # offset) moves over the same torus; both sides read the same texels

@@ -72,6 +72,48 @@ def test_config1_spawn_pose_is_degenerate_and_capped(mode):
     assert_planes_equal(got, want, "config1 spawn pose")
 
 
+def _signed_permutations():
+    """The 48 camera orientations whose matrix entries are 0 and +-1: every pixel of the middle column and
+    of the row with nc.y == 0 has a zero direction component, of either sign."""
+    import itertools
+    for perm in itertools.permutations(range(3)):
+        for signs in itertools.product((1.0, -1.0), repeat=3):
+            r = np.zeros((3, 3), np.float32)
+            for i in range(3):
+                r[i, perm[i]] = signs[i]
+            yield r
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_zero_direction_components_in_every_sign_and_position(mode):
+    """Rays with rd_k == +-0 from origins with integer, negative, near -1 and generic coordinates, through
+    a sparse random world around the origin (the voxels at coordinate -1, where the reference's NaN
+    arithmetic sends such rays, are inside the loaded area): spinning rays end at the cap, passive axes
+    continue as ordinary rays."""
+    rng = np.random.default_rng(11)
+    n, w, h = 64, 64, 48                                   # h*h / (2*w) = 18: row gy = 18 has nc.y == 0
+    block = (rng.random((n, n, n)) < 0.004).astype(np.uint8) * 3
+    world = O.World(block)
+    positions = [(0.0, 0.0, 0.0), (0.5, 0.5, 0.5), (-3.3, 2.2, -7.7), (-1.0, 5.0, 3.5), (5.5, -1.0, -2.0),
+                 (-0.5, -0.25, 7.0), (2.0, -6.5, -1.0)]
+    checked = capped = teleported = 0
+    with core_for(block, mode) as g:
+        for r in _signed_permutations():
+            for pos in positions:
+                m = np.zeros((4, 4), np.float32)           # column major: m[c] is column c
+                m[:3, :3] = r
+                m[3, :3] = pos
+                m[3, 3] = 1.0
+                cam = m.reshape(16)
+                want = O.trace(world, cam, w, h)
+                got = g.trace(cam, w, h)
+                assert_planes_equal(got, want, f"orientation {r.tolist()} position {pos}")
+                checked += 1
+                capped += int((want["face"] == -2).sum())
+                teleported += int((want["voxel"] == -1).any(axis=2).sum())
+    assert checked == 48 * len(positions) and capped > 1000 and teleported > 1000
+
+
 @pytest.mark.parametrize("mode", MODES)
 def test_config2_1080p_over_256(mode):
     p = scenes.pose_b()

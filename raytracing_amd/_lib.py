@@ -62,6 +62,8 @@ SYMBOLS = {
     "vrt_strip_rows": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "vrt_assemble_strips": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                       C.c_uint32]),
+    "vrt_alloc_host": (C.c_int, [_CTX, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "vrt_free_host": (C.c_int, [_CTX, C.c_void_p]),
     "vrt_sync": (C.c_int, [_CTX]),
     "vrt_download_world": (C.c_int, [_CTX, C.c_void_p, C.c_uint32]),
     "vrt_kernel_time": (C.c_int, [_CTX, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),

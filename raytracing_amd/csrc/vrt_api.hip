@@ -572,6 +572,27 @@ int vrt_assemble_strips(vrt_ctx *c, const void *gathered, void *frame, uint32_t 
     return VRT_OK;
 }
 
+int vrt_alloc_host(vrt_ctx *c, size_t bytes, void **out)
+{
+    if (!c || !out || bytes == 0) return fail(VRT_E_INVALID_ARG, "null argument or zero size");
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(c->device));
+    const hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return fail(VRT_E_OUT_OF_MEMORY, "hipHostMalloc(%zu) failed", bytes); }
+    HIP_TRY(e);
+    return VRT_OK;
+}
+
+int vrt_free_host(vrt_ctx *c, void *ptr)
+{
+    if (!c) return fail(VRT_E_INVALID_ARG, "null argument");
+    if (!ptr) return VRT_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // a copy into it may still be in flight
+    HIP_TRY(hipHostFree(ptr));
+    return VRT_OK;
+}
+
 int vrt_sync(vrt_ctx *c)
 {
     if (!c) return fail(VRT_E_INVALID_ARG, "null argument");

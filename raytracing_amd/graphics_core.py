@@ -48,8 +48,36 @@ class GraphicsCore:
     # -- lifetime ---------------------------------------------------------
     def close(self):
         if getattr(self, "_ctx", None):
+            for addr in getattr(self, "_host_blocks", []):
+                L.lib().vrt_free_host(self._ctx, addr)
+            self._host_blocks = []
             L.lib().vrt_destroy(self._ctx)
             self._ctx = None
+
+    def host_array(self, shape, dtype):
+        """A numpy array over page-locked host memory from the library (`vrt_alloc_host`), for output
+        planes that should come back at the bus rate.  Valid until close()."""
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape)) * dtype.itemsize
+        addr = C.c_void_p()
+        L.check(L.lib().vrt_alloc_host(self._ctx, max(nbytes, 1), C.byref(addr)))
+        if not hasattr(self, "_host_blocks"):
+            self._host_blocks = []
+        self._host_blocks.append(addr.value)
+        buf = (C.c_uint8 * max(nbytes, 1)).from_address(addr.value)
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def trace_into(self, cam, w, h, planes, y0=0, y1=None):
+        """Trace rows [y0,y1) into caller-provided host arrays (dict name -> contiguous numpy array)."""
+        y1 = h if y1 is None else y1
+        cam, camp = self._cam(cam)
+        for k, a in planes.items():
+            c, dt = _PLANES[k]
+            if a.dtype != dt or not a.flags.c_contiguous or a.size != (y1 - y0) * w * c:
+                raise ValueError(f"plane {k}: need a contiguous {np.dtype(dt).name} array of {(y1 - y0) * w * c} elements")
+        o = L.VrtOutputs(C.sizeof(L.VrtOutputs), L.MEM_HOST,
+                         *[planes[k].ctypes.data if k in planes else None for k in _PLANES])
+        L.check(L.lib().vrt_trace(self._ctx, camp, w, h, y0, y1, C.byref(o)))
 
     def __del__(self):
         try:

@@ -4,10 +4,13 @@ steps, bgra8) and, because both sides evaluate the same canonical binary32 expre
 order without FMA contraction, the float planes (t, hit_point, rgba) too (tolerance 0 ulp,
 compared as bit patterns).
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 
 import oracle_lib as O
+from raytracing_amd import _lib as L
 from raytracing_amd import (GraphicsCore, Player, TRACE_LITERAL, TRACE_SKIP, VOXEL_PACKED_U8,
                             VOXEL_REF_U16U16, VrtError, scenes)
 
@@ -273,6 +276,24 @@ def test_assemble_strips_moves_every_row_once(row_bytes, h, sh, parts, extra):
         assert e.value.code == -1
         with pytest.raises(VrtError):
             g.assemble_strips(d_src.data_ptr(), d_dst.data_ptr(), row_bytes, h, 0, parts, pad)
+
+
+def test_page_locked_output_planes(scene160):
+    cam = scenes.cam16(scenes.pose_b())
+    w, h = 320, 240
+    with core_for(scene160, TRACE_SKIP) as g:
+        want = g.trace(cam, w, h, outputs=("bgra8", "steps", "t"))
+        planes = {"bgra8": g.host_array((h, w, 4), np.uint8), "steps": g.host_array((h, w), np.uint32),
+                  "t": g.host_array((h, w), np.float32)}
+        for a in planes.values():
+            a[...] = 0
+        g.trace_into(cam, w, h, planes)
+        for k in planes:
+            assert np.array_equal(planes[k].view(np.uint32) if k == "t" else planes[k],
+                                  want[k].view(np.uint32) if k == "t" else want[k]), k
+        with pytest.raises(VrtError):
+            L.check(L.lib().vrt_alloc_host(g._ctx, 0, C.byref(C.c_void_p())))
+        L.check(L.lib().vrt_free_host(g._ctx, None))     # freeing nothing is fine
 
 
 def test_device_resident_outputs_match_host_outputs(scene160):

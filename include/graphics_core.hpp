@@ -25,6 +25,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <functional>
 #include <set>
 #include <stdexcept>
@@ -136,9 +137,13 @@ public:
         cfg.trace_mode   = VRT_TRACE_AUTO;
         check(vrt_create(&cfg, &ctx_));
         previous_frame_end = FrameToken{ctx_};
-        frame_.resize((size_t)width_ * height_ * 4);
+        resize(width_, height_);
     }
-    ~GraphicsCore() { vrt_destroy(ctx_); }
+    ~GraphicsCore()
+    {
+        vrt_free_host(ctx_, frame_.ptr);
+        vrt_destroy(ctx_);
+    }
     GraphicsCore(const GraphicsCore &) = delete;
     GraphicsCore &operator=(const GraphicsCore &) = delete;
 
@@ -156,7 +161,7 @@ public:
         vrt_outputs out{};
         out.struct_size = sizeof out;
         out.memory      = VRT_MEM_HOST;
-        out.bgra8       = frame_.data();
+        out.bgra8       = frame_.ptr;
         check(vrt_trace(ctx_, push_constants.transform.m, width_, height_, 0, height_, &out));
         return false;
     }
@@ -169,9 +174,27 @@ public:
     void resize(uint32_t width, uint32_t height)  // ≙ WindowEvent::Resized -> recreate_swapchain
     {
         width_ = width; height_ = height;
-        frame_.assign((size_t)width_ * height_ * 4, 0);
+        check(vrt_free_host(ctx_, frame_.ptr));
+        frame_ = Frame{};
+        const size_t bytes = (size_t)width_ * height_ * 4;
+        if (bytes == 0) return;
+        void *p = nullptr;
+        check(vrt_alloc_host(ctx_, bytes, &p));  // page-locked: the frame comes back at the bus rate
+        frame_.ptr = static_cast<uint8_t *>(p);
+        frame_.bytes = bytes;
+        std::memset(frame_.ptr, 0, bytes);
     }
-    const std::vector<uint8_t> &frame() const { return frame_; }  // B,G,R,A bytes, rows top to bottom
+    // B,G,R,A bytes, rows top to bottom, in page-locked host memory owned by the core
+    struct Frame {
+        uint8_t *ptr = nullptr;
+        size_t   bytes = 0;
+        const uint8_t *data() const { return ptr; }
+        size_t         size() const { return bytes; }
+        const uint8_t *begin() const { return ptr; }
+        const uint8_t *end() const { return ptr + bytes; }
+        uint8_t        operator[](size_t i) const { return ptr[i]; }
+    };
+    const Frame &frame() const { return frame_; }
     uint32_t width() const { return width_; }
     uint32_t height() const { return height_; }
     vrt_ctx *context() { return ctx_; }
@@ -186,7 +209,7 @@ private:
     vrt_ctx             *ctx_ = nullptr;
     GraphicsSettings     settings_;
     uint32_t             width_, height_;
-    std::vector<uint8_t> frame_;
+    Frame                frame_;
 };
 
 class Player {  // player/mod.rs:5-64

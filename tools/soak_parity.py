@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Long parity run (not part of pytest): many random poses over the procedural terrain, full frames,
 every output plane of the HIP skip kernel against the CPU oracle, bit for bit.
-usage: soak_parity.py [poses per world, default 40] [seed] [default|odd|sparse]   -> one summary line per world + total"""
+usage: soak_parity.py [poses per world, default 40] [seed] [default|odd|sparse|axis]   -> one summary line per world + total
+(axis: the default worlds seen along the axes -- yaw and pitch within 1e-3 of multiples of pi/2, often exactly on them, and
+positions with integer coordinates: direction components that are zero, or 1e-8, and plane parameters up to 1e11)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -23,6 +25,7 @@ WORLDS = {"default": [(160, VOXEL_REF_U16U16, np.uint16, 640, 480), (256, VOXEL_
 kind = sys.argv[3] if len(sys.argv) > 3 else "default"
 WORLDS["sparse"] = [(64, VOXEL_PACKED_U8, np.uint8, 640, 360), (160, VOXEL_REF_U16U16, np.uint16, 640, 480),
                     (256, VOXEL_PACKED_U8, np.uint8, 960, 540)]
+WORLDS["axis"] = WORLDS["default"]
 for n, fmt, dtype, w, h in WORLDS[kind]:
     centre = np.array([rng.uniform(-200, 200), 20.0, rng.uniform(-200, 200)], np.float32)
     wmin = scenes.window_min(centre, n)
@@ -43,7 +46,13 @@ for n, fmt, dtype, w, h in WORLDS[kind]:
             # any position inside the chunk the window was built for, any yaw, pitch from straight down to up
             pos = (np.array(base_chunk, np.float32) * 32 + rng.uniform(0.01, 31.99, 3)).astype(np.float32)
             if i % 3 == 0: pos[1] = np.float32(base_chunk[1] * 32 + rng.uniform(0.01, 12.0))   # near / under the surface
-            p = Player.at(pos, float(rng.uniform(-3.2, 3.2)), float(rng.uniform(-1.5, 1.5)))
+            yaw, pitch = float(rng.uniform(-3.2, 3.2)), float(rng.uniform(-1.5, 1.5))
+            if kind == "axis":
+                eps = [0.0, 0.0, 1e-7, -1e-7, 1e-5, -1e-5, 1e-3, -1e-3]
+                yaw = float(rng.integers(-2, 3)) * (np.pi / 2) + eps[rng.integers(0, 8)]
+                pitch = float(rng.integers(-1, 2)) * (np.pi / 2) * (1.0 if rng.random() < 0.3 else 0.0) + eps[rng.integers(0, 8)]
+                if i % 2 == 0: pos = np.floor(pos) + np.float32(rng.integers(0, 2)) * np.float32(0.5)   # integer / half-integer coordinates
+            p = Player.at(pos, yaw, pitch)
             cam = scenes.cam16(p)
             got = g.trace(cam, w, h)
             want = O.trace(world, cam, w, h)

@@ -3,7 +3,7 @@
 world): any yaw, pitch from straight down to straight up, a third of the positions near or under the
 surface, heights up to 400 voxels.  Prints the distribution and the slowest poses, to find frames that
 cost far more than the bench frame.
-usage: pose_sweep.py [poses, default 200] [seed]"""
+usage: pose_sweep.py [poses, default 200] [seed] [random|axis]   (axis: yaw / pitch on or near multiples of pi/2)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -27,6 +27,11 @@ with GraphicsCore(grid_n=N, voxel_format=VOXEL_PACKED_U8, trace_mode=TRACE_SKIP)
         elif kind == 1: pos[1] = np.float32(rng.uniform(12.0, 80.0))
         else: pos[1] = np.float32(rng.uniform(80.0, 400.0))
         yaw, pitch = float(rng.uniform(-3.2, 3.2)), float(rng.uniform(-1.5, 1.5))
+        if len(sys.argv) > 3 and sys.argv[3] == "axis":
+            eps = [0.0, 0.0, 1e-7, -1e-7, 1e-5, -1e-5, 1e-3, -1e-3]
+            yaw = float(rng.integers(-2, 3)) * (np.pi / 2) + eps[rng.integers(0, 8)]
+            pitch = float(rng.integers(-1, 2)) * (np.pi / 2) * (1.0 if rng.random() < 0.3 else 0.0) + eps[rng.integers(0, 8)]
+            if i % 2 == 0: pos = np.floor(pos) + np.float32(rng.integers(0, 2)) * np.float32(0.5)
         cam = scenes.cam16(Player.at(pos, yaw, pitch))
         for _ in range(4):   # lets the dispatch order settle
             g.trace_device(cam, W, H, 0, H, {"bgra8": frame.data_ptr(), "steps": steps.data_ptr()})

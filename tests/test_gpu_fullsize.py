@@ -1,4 +1,4 @@
-"""Parity at BASELINE sizes and under window movement.
+"""Parity at the full benchmark sizes and under window movement.
 
 * 1920x1080 over the 1024^3 u8 terrain (the bench workload): the skip kernel against the
   literal kernel on every pixel (both GPU; the literal kernel is itself checked against

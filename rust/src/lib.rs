@@ -24,7 +24,7 @@ fn check(rc: i32) {
 #[repr(C)]
 #[derive(Clone, Copy)]
 pub struct PushConstants {
-    pub cam_transform: Matrix4<f32>, // column major, like GLSL's mat4
+    pub transform: Matrix4<f32>, // column major, like GLSL's mat4
     pub image_index: u32,
 }
 
@@ -95,7 +95,8 @@ impl GraphicsCore {
     }
 
     /// src/graphics/mod.rs:245 -- the terrain generator for one chunk, stored at its toroidal texels
-    pub fn upload_chunk_gpu(&mut self, chunk_pos: Vector3<i32>) {
+    /// (the second argument is the reference's `&mut GameState`, which it does not use either)
+    pub fn upload_chunk_gpu<G>(&mut self, chunk_pos: Vector3<i32>, _game_state: &mut G) {
         check(unsafe { vrt_sys::vrt_generate_chunk(self.ctx, chunk_pos.x, chunk_pos.y, chunk_pos.z) });
     }
 
@@ -103,6 +104,13 @@ impl GraphicsCore {
     pub fn reset_distance_field(&mut self) {
         check(unsafe { vrt_sys::vrt_reset_distance_field(self.ctx) });
         self.previous_frame_end = Some(FrameToken(self.ctx));
+    }
+
+    /// What game_state.rs:79 builds with `vulkano::sync::now(core.device.clone()).boxed()`: that line names
+    /// vulkano itself and is the one line of game_logic that has to change, to
+    /// `core.previous_frame_end = Some(core.fresh_frame_token());`
+    pub fn fresh_frame_token(&self) -> FrameToken {
+        FrameToken(self.ctx)
     }
 
     /// src/graphics/mod.rs:531 -- returns the frame (rows top to bottom, bytes B, G, R, A)
@@ -120,7 +128,7 @@ impl GraphicsCore {
         };
         // nalgebra's Matrix4<f32> is column major: as_slice() is the 16 floats the ABI wants
         check(unsafe {
-            vrt_sys::vrt_trace(self.ctx, push_constants.cam_transform.as_slice().as_ptr(), self.width, self.height, 0,
+            vrt_sys::vrt_trace(self.ctx, push_constants.transform.as_slice().as_ptr(), self.width, self.height, 0,
                                self.height, &out)
         });
         self.previous_frame_end = Some(FrameToken(self.ctx));

@@ -585,9 +585,10 @@ struct CellRay {
 // The box algebra needs non-zero directions and finite plane parameters.
 VRT_DEV bool ray_is_regular(float rdx, float rdy, float rdz)
 {
+    // (all three reciprocals are taken on every path, so that the traversal's own 1 / rd are these)
     const float big = 0x1.0p100f;
-    return (rdx != 0.0f) && (rdy != 0.0f) && (rdz != 0.0f) && (fabsf(1.0f / rdx) < big) && (fabsf(1.0f / rdy) < big) &&
-           (fabsf(1.0f / rdz) < big);
+    const float ix = fabsf(1.0f / rdx), iy = fabsf(1.0f / rdy), iz = fabsf(1.0f / rdz);
+    return ((rdx != 0.0f) & (rdy != 0.0f) & (rdz != 0.0f) & (ix < big) & (iy < big) & (iz < big)) != 0;
 }
 
 // a ray for which ray_is_regular holds

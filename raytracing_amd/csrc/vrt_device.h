@@ -52,6 +52,24 @@ VRT_DEV int argmin3(float a, float b, float c)
     return idx;
 }
 
+// 1 / x for the direction components of an ordinary ray: the compiler's own division sequence (reciprocal
+// estimate, one Newton step, two quotient corrections, all fused multiply-adds) without the operand
+// scaling and the special-case fix-up around it.  Those only act on operands whose quotient is zero, denormal,
+// infinite or NaN, so for every x with |x| <= 2 and |1 / x| < 2^100 the result has the bits of 1.0f / x, and
+// for every other such x (and NaN) it is not below 2^100 in magnitude either -- which is all the traversal
+// asks (ray_is_regular; a component of a normalised direction never exceeds 1).  vrt_selftest_recip checks
+// both statements for every such argument.
+VRT_DEV float recip_regular(float x)
+{
+    float       r = __builtin_amdgcn_rcpf(x);
+    const float e = __builtin_fmaf(-x, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    float rem = __builtin_fmaf(-x, r, 1.0f);
+    float q   = __builtin_fmaf(rem, r, r);
+    rem = __builtin_fmaf(-x, q, 1.0f);
+    return __builtin_fmaf(rem, r, q);
+}
+
 // Canonical sine of the shading term (raytrace.glsl:130), binary32 throughout: k = rint(x/pi),
 // reduction against pi = P1 + P2 + P3 with P1 = 3.125 (k*P1 and x - k*P1 are exact for
 // |k| < 2^19), odd Taylor polynomial through r^11.  |error| < 3e-7 for |x| < 2^20.

@@ -445,7 +445,11 @@ struct CellRay {
         smx = px ? 0 : -1; smy = py ? 0 : -1; smz = pz ? 0 : -1;
         rnx = zx ? far : (px ? rox : -rox); rny = zy ? far : (py ? roy : -roy); rnz = zz ? far : (pz ? roz : -roz);
         dnx = zx ? -rdx : fabsf(rdx); dny = zy ? -rdy : fabsf(rdy); dnz = zz ? -rdz : fabsf(rdz);
-        inx = fabsf(1.0f / rdx); iny = fabsf(1.0f / rdy); inz = fabsf(1.0f / rdz);  // +inf on a frozen axis
+        if (MAY_FREEZE) {
+            inx = fabsf(1.0f / rdx); iny = fabsf(1.0f / rdy); inz = fabsf(1.0f / rdz);  // +inf on a frozen axis
+        } else {  // ray_is_regular holds: the same bits, and the same instructions as in that test
+            inx = fabsf(recip_regular(rdx)); iny = fabsf(recip_regular(rdy)); inz = fabsf(recip_regular(rdz));
+        }
         lnx = px ? lox : -lox; lny = py ? loy : -loy; lnz = pz ? loz : -loz;
         const int oct = (px ? 1 : 0) | (py ? 2 : 0) | (pz ? 4 : 0);
         dshift = 8 * (oct & 3) + (oct >= 4 ? 32 : 0);
@@ -587,7 +591,7 @@ VRT_DEV bool ray_is_regular(float rdx, float rdy, float rdz)
 {
     // (all three reciprocals are taken on every path, so that the traversal's own 1 / rd are these)
     const float big = 0x1.0p100f;
-    const float ix = fabsf(1.0f / rdx), iy = fabsf(1.0f / rdy), iz = fabsf(1.0f / rdz);
+    const float ix = fabsf(recip_regular(rdx)), iy = fabsf(recip_regular(rdy)), iz = fabsf(recip_regular(rdz));
     return ((rdx != 0.0f) & (rdy != 0.0f) & (rdz != 0.0f) & (ix < big) & (iy < big) & (iz < big)) != 0;
 }
 

@@ -84,3 +84,11 @@ def test_rust_declarations_name_every_symbol():
     text = open(os.path.join(root, "rust", "src", "vrt_sys.rs")).read()
     rust = sorted(set(re.findall(r"pub fn (vrt_[a-z_0-9]+)\s*\(", text)))
     assert rust == declared_symbols()
+
+
+def test_selftest_library_loads():
+    import ctypes as C
+    import os
+    from raytracing_amd import _lib as L
+    lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(L.__file__)), "libvrt_selftest.so"))
+    assert hasattr(lib, "vrt_selftest_recip")

@@ -75,6 +75,19 @@ def test_config1_spawn_pose_is_degenerate_and_capped(mode):
     assert_planes_equal(got, want, "config1 spawn pose")
 
 
+def test_fast_reciprocal_is_the_division_for_every_float():
+    """recip_regular (the kernels' 1 / rd of ordinary rays) against 1.0f / x on the device for every float of
+    magnitude up to 2 and every NaN: identical bits wherever |1 / x| < 2^100, and the same
+    side of that bound everywhere else."""
+    import os
+    lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(L.__file__)), "libvrt_selftest.so"))
+    lib.vrt_selftest_recip.restype = C.c_int
+    lib.vrt_selftest_recip.argtypes = [C.c_int, C.POINTER(C.c_ulonglong)]
+    out = (C.c_ulonglong * 3)()
+    assert lib.vrt_selftest_recip(0, out) == 0
+    assert (out[0], out[1]) == (0, 0), f"values differ for {out[0]} arguments, classes for {out[1]}; first 0x{out[2]:08x}"
+
+
 def _signed_permutations():
     """The 48 camera orientations whose matrix entries are 0 and +-1: every pixel of the middle column and
     of the row with nc.y == 0 has a zero direction component, of either sign."""

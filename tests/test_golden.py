@@ -61,3 +61,31 @@ def test_gpu_matches_golden(path):
         out = g.trace(cam, fx["width"], fx["height"])
         sec = g.trace_secondary(cam, fx["width"], fx["height"])
     check(fx, block, out, sec)
+
+
+FULLSIZE = sorted(glob.glob(os.path.join(HERE, "golden", "fullsize", "*.json")))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", FULLSIZE, ids=[os.path.basename(p)[:-5] for p in FULLSIZE])
+def test_gpu_matches_fullsize_golden(path):
+    """The benchmark frame (made by tests/golden/make_golden_fullsize.py: the oracle's trace of the 1024^3
+    world): every plane of the HIP path, primary and secondary, has the oracle's SHA-256."""
+    from raytracing_amd import GraphicsCore, VOXEL_PACKED_U8
+    fx = json.load(open(path))
+    cam = np.array(fx["cam_col_major_bits"], np.uint32).view(np.float32)
+    with GraphicsCore(grid_n=fx["grid_n"], voxel_format=VOXEL_PACKED_U8) as g:
+        g.generate_window(fx["window_min"])
+        g.reset_distance_field()
+        assert sha(g.download_world()) == fx["sha256"]["block"]
+        out = g.trace(cam, fx["width"], fx["height"])
+        sec = g.trace_secondary(cam, fx["width"], fx["height"])
+    for k in ("voxel", "face", "steps", "bgra8", "t", "hit_point", "rgba"):
+        assert sha(out[k]) == fx["sha256"][k], k
+    for k in ("shadow", "ao", "sec_steps"):
+        assert sha(sec[k]) == fx["sha256"][k], k
+    assert int(out["steps"].astype(np.int64).sum()) == fx["totals"]["steps"]
+    for p in fx["pixels"]:
+        r, c = p["row"], p["col"]
+        assert out["voxel"][r, c].tolist() == p["voxel"] and int(out["face"][r, c]) == p["face"]
+        assert int(out["t"][r, c].view(np.uint32)) == p["t_bits"] and int(sec["sec_steps"][r, c]) == p["sec_steps"]

@@ -307,6 +307,15 @@ def main():
             line["roofline"]["limiter"] = limiter
         copy_gbs = copy_bandwidth_gbs()
         line["roofline"]["measured_copy"] = {"GB/s": copy_gbs, "frac": achieved / copy_gbs}
+        # the frame just timed against the frozen oracle output for this pose (tests/golden/fullsize)
+        gold = os.path.join(ROOT, "tests", "golden", "fullsize", "headline_1080p_n1024.json")
+        if os.path.exists(gold) and core.last_kernel_name() in ("skip", "literal"):
+            import hashlib
+            fx = json.load(open(gold))
+            if np.array_equal(np.asarray(fx["cam_col_major_bits"], np.uint32), np.asarray(cam, np.float32).view(np.uint32)):
+                last = frames[(counter[0] - 1) & 1].cpu().numpy()
+                line["parity"] = {"bgra8_sha256_equals_oracle_golden": hashlib.sha256(last.tobytes()).hexdigest() == fx["sha256"]["bgra8"],
+                                  "steps_sum_equals_oracle_golden": sum_steps == fx["totals"]["steps"] if not strips else None}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(core, cam, steps_np)
         print(json.dumps(line), flush=True)

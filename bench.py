@@ -9,7 +9,7 @@ BGRA8 store) through libvrt.so.  The world (default procedural terrain over the 
 window around the camera) is generated on the GPU and indexed once, before timing, and
 stays resident in HBM.  With N > 1 every rank holds a replica of the world and traces a
 frame of its own camera pose (weak scaling); the BGRA8 framebuffers are gathered to rank
-0 over RCCL inside the timed region.  `--shard strips` is the other partition of the path: ONE
+0 over RCCL inside the timed region, `--gather-every` frames per gather.  `--shard strips` is the other partition of the path: ONE
 frame dealt to the ranks in interleaved 16-row strips (strong scaling), gathered and put back
 in row order on rank 0 by the library's copy kernel.
 
@@ -113,6 +113,10 @@ def main():
     ap.add_argument("--shard", choices=["poses", "strips"], default="poses",
                     help="poses (the headline job): one frame of its own pose per rank, weak scaling; strips: ONE frame "
                          "dealt to the ranks in interleaved 16-row strips, gathered and put back in row order on rank 0")
+    ap.add_argument("--gather-every", type=int, default=4,
+                    help="frames per gather (pose sharding, N > 1): each rank fills a buffer of this many frames and hands it "
+                         "to one gather, which overlaps the tracing of the next buffer; every frame still reaches rank 0 "
+                         "inside the timed region.  1 = one gather per frame")
     ap.add_argument("--time-every", type=int, default=8,
                     help="bracket one frame in this many with HIP events (the events themselves cost stream time)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -162,10 +166,16 @@ def main():
     # two frame buffers: the gather of frame k overlaps the trace of frame k+1
     frames = [torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
     steps_t = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+    # pose sharding with N > 1: two buffers of G frames each; the gather of one overlaps the tracing into the other
+    G = max(1, args.gather_every)
     gathered = [None, None]
-    if multi and rank == 0:
-        gathered = [[torch.zeros((H, W, 4), dtype=torch.uint8, device="cpu" if host else "cuda") for _ in range(world)]
-                    for _ in range(2)]
+    batch = None
+    if multi and not strips:
+        batch = [torch.zeros((G, H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+        if rank == 0:
+            gathered = [[torch.zeros((G, H, W, 4), dtype=torch.uint8, device="cpu" if host else "cuda") for _ in range(world)]
+                        for _ in range(2)]
+    fill = {"buf": 0, "n": 0, "last": (0, 0)}   # buffer being filled, frames in it, (buffer, slot) of the last frame traced
     if strips:
         pad_rows = sharding.max_strip_rows(H, STRIP_H, world)
         packed = [torch.zeros((pad_rows, W, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
@@ -213,21 +223,35 @@ def main():
                         pending[b] = None
                         core.assemble_strips(parts_buf[b].data_ptr(), frames[b].data_ptr(), W * 4, H, STRIP_H, world,
                                              pad_rows)
-        elif multi and not host:
-            with torch.cuda.stream(stream):
-                if pending[b] is not None:
-                    pending[b].wait()                # the trace below may overwrite frames[b] only after its gather
-                core.trace_device(cam, W, H, 0, H, {"bgra8": frames[b].data_ptr()})
-                # RCCL gather to rank 0, ordered behind the trace on the context's stream
-                pending[b] = dist.gather(frames[b], gathered[b], dst=0, async_op=True)
         elif multi:
-            core.trace_device(cam, W, H, 0, H, {"bgra8": frames[b].data_ptr()})
-            core.sync()
-            dist.gather(frames[b].cpu(), gathered[b], dst=0)
+            b, j = fill["buf"], fill["n"]
+            with torch.cuda.stream(stream):
+                if j == 0 and pending[b] is not None:
+                    pending[b].wait()                # the traces below may overwrite batch[b] only after its gather
+                    pending[b] = None
+                core.trace_device(cam, W, H, 0, H, {"bgra8": batch[b][j].data_ptr()})
+            fill["n"], fill["last"] = j + 1, (b, j)
+            if fill["n"] == G:
+                flush()
         else:
             core.trace_device(cam, W, H, 0, H, {"bgra8": frames[b].data_ptr()})
 
+    def flush():
+        """Hand the buffer being filled to the gather (a partial buffer goes whole: its tail holds older frames)."""
+        b = fill["buf"]
+        if batch is None or fill["n"] == 0:
+            return
+        if host:
+            core.sync()
+            dist.gather(batch[b].cpu(), gathered[b], dst=0)
+        else:
+            with torch.cuda.stream(stream):
+                # RCCL gather to rank 0, ordered behind the traces on the context's stream
+                pending[b] = dist.gather(batch[b], gathered[b], dst=0, async_op=True)
+        fill["buf"], fill["n"] = b ^ 1, 0
+
     def fence():
+        flush()
         for b in range(2):
             if pending[b] is not None:
                 with torch.cuda.stream(stream):
@@ -294,7 +318,8 @@ def main():
             "config": {"workload": "1920x1080 primary rays over 1024^3 u8 procedural terrain (pose B at y=40.3), "
                                    + ("world replicated per GPU, ONE frame dealt in interleaved 16-row strips, "
                                       "BGRA8 gather + row reorder on rank 0" if strips else
-                                      "world replicated per GPU, one pose per GPU, BGRA8 gather to rank 0"),
+                                      "world replicated per GPU, one pose per GPU, BGRA8 gather to rank 0"
+                                      + (f" ({G} frames per gather)" if multi else "")),
                        "kernel": core.last_kernel_name(), "grid_n": N_GRID, "width": W, "height": H,
                        "world_build_s": round(build_s, 3)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -313,7 +338,7 @@ def main():
             import hashlib
             fx = json.load(open(gold))
             if np.array_equal(np.asarray(fx["cam_col_major_bits"], np.uint32), np.asarray(cam, np.float32).view(np.uint32)):
-                last = frames[(counter[0] - 1) & 1].cpu().numpy()
+                last = (batch[fill["last"][0]][fill["last"][1]] if batch is not None else frames[(counter[0] - 1) & 1]).cpu().numpy()
                 line["parity"] = {"bgra8_sha256_equals_oracle_golden": hashlib.sha256(last.tobytes()).hexdigest() == fx["sha256"]["bgra8"],
                                   "steps_sum_equals_oracle_golden": sum_steps == fx["totals"]["steps"] if not strips else None}
         if world == 1 and not args.no_cpu_baseline:
@@ -326,9 +351,10 @@ def main():
         core.trace_device(cam, W, H, 0, H, {"bgra8": whole.data_ptr()})
         core.sync()
         assert torch.equal(frames[(counter[0] - 1) & 1], whole), "strips did not reassemble to the frame"
-    elif multi and rank == 0 and not host:
+    elif multi and rank == 0:
         # the last gathered frame of rank 0 is its own last frame
-        assert torch.equal(gathered[(counter[0] - 1) & 1][0], frames[(counter[0] - 1) & 1]), "gather returned another frame"
+        lb, lj = fill["last"]
+        assert torch.equal(gathered[lb][0][lj].cpu(), batch[lb][lj].cpu()), "gather returned another frame"
     core.close()
     if multi:
         dist.destroy_process_group()

@@ -151,6 +151,27 @@ def test_step_cap_on_degenerate_ray():
     assert r["capped"] == 0 and r["steps"] == 1 and r["voxel"] == (-1, 16, 16)
 
 
+def test_zero_component_that_never_wins_is_a_plain_2d_walk():
+    # rd.x = -0: inv.x = -inf, check_point.x = anchor.x = 16, t.x = (16 - 16.5)*(-inf) = +inf never wins argmin,
+    # and ro.x + (-0)*t = 16.5 keeps anchor.x.  y planes 17, 18, 19 at t = .5, 1.5, 2.5; z planes 17, 18 at t = 1, 3.
+    # visited: (16,17,16) .5 [y], (16,17,17) 1 [z], (16,18,17) 1.5 [y], (16,19,17) 2.5 [y]
+    r = both(solid_at(32, [(16, 19, 17)], value=5), RO, (-0.0, 1.0, 0.5))
+    assert r["hit"] == 1 and r["steps"] == 4 and r["voxel"] == (16, 19, 17) and r["block_id"] == 5
+    assert r["face"] == 2 and r["t"] == f32(2.5)          # normal = -y
+    assert tuple(r["hit_point"]) == (16.5, 19.0, 17.75)
+
+
+def test_zero_component_that_wins_once_moves_the_anchor_to_minus_one():
+    # rd.x = +0, ro.x = -5.5 (chunk -1: window x in (-48, 15), n = 64).  Iteration 1: t.x = (-6 + 5.5)*inf = -inf
+    # wins, the position is NaN on x, anchor.x = f2i(NaN) - 1 + 0 = -1 (raytrace.glsl:50), y and z keep 16; voxel
+    # (-1,16,16) is air.  From there t.x = (-1 + 5.5)*inf = +inf never wins again and the ray walks y and z as
+    # above, at x = -1: (-1,17,16) .5, (-1,17,17) 1, (-1,18,17) 1.5, (-1,19,17) 2.5 -- five iterations in all.
+    r = both(solid_at(64, [(-1, 19, 17)], value=9), (-5.5, 16.5, 16.5), (0.0, 1.0, 0.5))
+    assert r["hit"] == 1 and r["steps"] == 5 and r["voxel"] == (-1, 19, 17) and r["block_id"] == 9
+    assert r["face"] == 2 and r["t"] == f32(2.5)
+    assert tuple(r["hit_point"]) == (-5.5, 19.0, 17.75)
+
+
 def test_free_dist_general_formula():
     # documentation of the unfinished upstream skip (never active as shipped): with
     # free_dist = 2 at the start voxel the first iteration jumps to the far face of the

@@ -88,6 +88,28 @@ def test_fast_reciprocal_is_the_division_for_every_float():
     assert (out[0], out[1]) == (0, 0), f"values differ for {out[0]} arguments, classes for {out[1]}; first 0x{out[2]:08x}"
 
 
+@pytest.mark.parametrize("mode", MODES)
+def test_transforms_that_are_not_rotations(scene160, mode):
+    """The ABI takes any finite 4x4: scaled, sheared and mirrored bases, a bottom row that is not (0,0,0,1)
+    (the `w` term of raytrace.glsl:122 then adds to the direction), huge and tiny scales.  The direction is
+    normalised either way; both sides must agree on every plane."""
+    rng = np.random.default_rng(5)
+    base = np.array(scenes.cam16(scenes.pose_b()), np.float32).reshape(4, 4).copy()   # [column][row]
+    variants = []
+    for scale in (100.0, 0.01, 1e-12, 3e12):
+        m = base.copy(); m[:3, :3] *= np.float32(scale); variants.append(m)
+    m = base.copy(); m[0, :3] *= -1.0; variants.append(m)                      # mirrored
+    m = base.copy(); m[1, :3] += 0.7 * m[0, :3]; variants.append(m)            # sheared
+    m = base.copy(); m[:3, 3] = (0.3, -0.2, 0.1); variants.append(m)           # bottom row of the 3 direction columns
+    for _ in range(3):
+        m = base.copy(); m[:3, :3] = rng.normal(size=(3, 3)).astype(np.float32); variants.append(m)
+    world = O.World(scene160)
+    with core_for(scene160, mode) as g:
+        for i, m in enumerate(variants):
+            cam = m.reshape(16)
+            assert_planes_equal(g.trace(cam, 160, 120), O.trace(world, cam, 160, 120), f"transform variant {i}")
+
+
 def _signed_permutations():
     """The 48 camera orientations whose matrix entries are 0 and +-1: every pixel of the middle column and
     of the row with nc.y == 0 has a zero direction component, of either sign."""

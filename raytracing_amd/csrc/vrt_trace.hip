@@ -971,6 +971,33 @@ VRT_DEV void secondary_dir(unsigned pixel_index, unsigned index, int face, float
     dz = k == 2 ? nz : (k == 1 ? tx : ty);
 }
 
+// The secondary-ray kernel keeps its seldom used code out of line for the same reason as k_trace_skip
+// (degenerate_pixel): a ray with a zero direction component goes through the complete traversal in a
+// function of its own, which reads the launch parameters through the kernel-argument pointer.
+// Primary ray of pixel (gx, gy): bit 0 hit, bits 1..2 axis, bit 3 s11 < 0; hit point in hp[0..2].
+template <typename T, int FORM>
+__device__ __attribute__((noinline)) unsigned degenerate_primary(const TraceParams *params, unsigned gx, unsigned gy, float *hp)
+{
+    const TraceParams &P = *params;
+    float rdx, rdy, rdz;
+    raygen(P, gx, gy, rdx, rdy, rdz);
+    RayHit H;
+    traverse_auto<T, FORM>(P, P.m[12], P.m[13], P.m[14], rdx, rdy, rdz, P.lo[0], P.lo[1], P.lo[2], P.up[0], P.up[1], P.up[2], H);
+    hp[0] = H.hx; hp[1] = H.hy; hp[2] = H.hz;
+    return (H.hit ? 1u : 0u) | ((unsigned)H.k << 1) | (H.sk < 0 ? 8u : 0u);
+}
+
+// Any ray in the camera's loaded area: bit 31 hit, the loop iterations below it.
+template <typename T, int FORM>
+__device__ __attribute__((noinline)) unsigned degenerate_ray(const TraceParams *params, float rox, float roy, float roz,
+                                                             float rdx, float rdy, float rdz)
+{
+    const TraceParams &P = *params;
+    RayHit S;
+    traverse_auto<T, FORM>(P, rox, roy, roz, rdx, rdy, rdz, P.lo[0], P.lo[1], P.lo[2], P.up[0], P.up[1], P.up[2], S);
+    return (S.hit ? 0x80000000u : 0u) | min(S.steps, 0x7fffffffu);
+}
+
 // (eight wavefronts per SIMD here too: 336 us per 1080p frame with secondaries against 359 us with the 85
 // VGPRs and five wavefronts the compiler takes unasked, 343 us with six)
 template <typename T, int FORM>
@@ -985,8 +1012,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         const float rox = P.m[12], roy = P.m[13], roz = P.m[14];
         // loaded area (raytrace.glsl:19-24), evaluated once per frame on the host
         const int lox = P.lo[0], loy = P.lo[1], loz = P.lo[2], upx = P.up[0], upy = P.up[1], upz = P.up[2];
+        const TraceParams *params = (const TraceParams *)__builtin_amdgcn_kernarg_segment_ptr();  // P sits at offset 0
         RayHit H;
-        traverse_auto<T, FORM>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
+        if (FORM == FORM_CAPPED) {
+            traverse_skip<T>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
+        } else if (ray_is_regular(rdx, rdy, rdz)) {
+            traverse_cells_regular<T, FORM == FORM_POW2>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, H);
+        } else {
+            float hp[3];
+            const unsigned r = degenerate_primary<T, FORM>(params, gx, gy, hp);
+            H.hit = (int)(r & 1u); H.k = (int)((r >> 1) & 3u); H.sk = (r & 8u) ? -1 : 1;
+            H.hx = hp[0]; H.hy = hp[1]; H.hz = hp[2]; H.work = 0;
+        }
         unsigned sh = 0, occ = 0, st = 0;
         work = H.work;
         if (H.hit) {
@@ -1015,7 +1052,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 float sdx, sdy, sdz;
                 secondary_dir(row * P.w + col, s, face, sdx, sdy, sdz);
                 RayHit S;
-                traverse_auto<T, FORM>(P, sox, soy, soz, sdx, sdy, sdz, lox, loy, loz, upx, upy, upz, S);
+                if (FORM == FORM_CAPPED) {
+                    traverse_skip<T>(P, sox, soy, soz, sdx, sdy, sdz, lox, loy, loz, upx, upy, upz, S);
+                } else if (ray_is_regular(sdx, sdy, sdz)) {
+                    traverse_cells_regular<T, FORM == FORM_POW2>(P, sox, soy, soz, sdx, sdy, sdz, lox, loy, loz, S);
+                } else {
+                    const unsigned r = degenerate_ray<T, FORM>(params, sox, soy, soz, sdx, sdy, sdz);
+                    S.hit = (int)(r >> 31); S.steps = r & 0x7fffffffu; S.work = 0;
+                }
                 st += S.steps;
                 work += S.work;
                 if (S.hit) { if (s == 0) sh = 1; else ++occ; }

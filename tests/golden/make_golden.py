@@ -58,7 +58,18 @@ def freeze(name, n, dtype, player, w, h, samples=256, seed=1):
     print(name, fx["totals"])
 
 
+def freeze_flythrough_poses():
+    """The 64 camera transforms of the 2048^3 flythrough (tests/golden/fullsize/flythrough_poses_64x16_f32.json)."""
+    cams = np.stack([np.asarray(scenes.cam16(p), np.float32) for p in scenes.flythrough_poses(64)])
+    note = ("64 camera transforms of the flythrough (circle of radius 300 voxels at y = 60.3, yaw_k = 2*pi*k/64 + 0.013, "
+            "pitch -0.3), column major, as uint32 bit patterns of the 16 f32 each; made from "
+            "raytracing_amd.scenes.flythrough_poses(64) by tests/golden/make_golden.py")
+    with open(os.path.join(HERE, "fullsize", "flythrough_poses_64x16_f32.json"), "w") as f:
+        json.dump({"note": note, "cam_col_major_bits": cams.view(np.uint32).tolist()}, f)
+
+
 if __name__ == "__main__":
+    freeze_flythrough_poses()
     freeze("config1_pose_b_640x480_n160", 160, np.uint16, scenes.pose_b(), 640, 480)
     freeze("config1_spawn_640x480_n160", 160, np.uint16, scenes.pose_spawn(), 640, 480)
     freeze("config2_pose_b_1920x1080_n256", 256, np.uint16, scenes.pose_b(), 1920, 1080)

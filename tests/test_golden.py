@@ -63,7 +63,7 @@ def test_gpu_matches_golden(path):
     check(fx, block, out, sec)
 
 
-FULLSIZE = sorted(glob.glob(os.path.join(HERE, "golden", "fullsize", "*.json")))
+FULLSIZE = sorted(glob.glob(os.path.join(HERE, "golden", "fullsize", "headline_*.json")))
 
 
 @pytest.mark.gpu
@@ -89,3 +89,12 @@ def test_gpu_matches_fullsize_golden(path):
         r, c = p["row"], p["col"]
         assert out["voxel"][r, c].tolist() == p["voxel"] and int(out["face"][r, c]) == p["face"]
         assert int(out["t"][r, c].view(np.uint32)) == p["t_bits"] and int(sec["sec_steps"][r, c]) == p["sec_steps"]
+
+
+def test_flythrough_poses_match_the_committed_fixture():
+    """The 64 x 16 f32 camera transforms of the pose-sharded flythrough, bit for bit."""
+    from raytracing_amd import scenes
+    fx = json.load(open(os.path.join(HERE, "golden", "fullsize", "flythrough_poses_64x16_f32.json")))
+    want = np.array(fx["cam_col_major_bits"], np.uint32)
+    got = np.stack([np.asarray(scenes.cam16(p), np.float32) for p in scenes.flythrough_poses(64)]).view(np.uint32)
+    assert want.shape == (64, 16) and np.array_equal(got, want)

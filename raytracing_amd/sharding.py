@@ -21,6 +21,12 @@ def max_strip_rows(h, strip_h, parts):
     return max(len(strip_rows(h, strip_h, p, parts)) for p in range(parts))
 
 
+def pose_indices(count, part, parts):
+    """Poses of a flythrough traced by `part`: pose k belongs to part k % parts (neighbouring poses look
+    alike, so dealing them round keeps the parts' work alike too)."""
+    return list(range(part, count, parts))
+
+
 def gather_frame(packed, h, strip_h, dst=0, group=None, out=None, core=None):
     """Gather every rank's packed rows (tensor [rows_r, ...]) to `dst` and return the full
     frame [h, ...] there (None elsewhere).  Ranks own different row counts when the strip

@@ -74,3 +74,11 @@ def test_strip_rows_cover_the_frame_once():
     for h, sh, parts in [(2160, 16, 8), (1080, 8, 4), (480, 16, 3), (40, 16, 2)]:
         allrows = np.concatenate([sharding.strip_rows(h, sh, p, parts) for p in range(parts)])
         assert sorted(allrows.tolist()) == list(range(h))
+
+
+def test_pose_sharding_covers_every_pose_once():
+    for count, parts in [(64, 8), (64, 3), (5, 8), (1, 1)]:
+        dealt = [k for part in range(parts) for k in sharding.pose_indices(count, part, parts)]
+        assert sorted(dealt) == list(range(count))
+        sizes = [len(sharding.pose_indices(count, part, parts)) for part in range(parts)]
+        assert max(sizes) - min(sizes) <= 1

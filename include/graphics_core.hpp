@@ -136,6 +136,7 @@ public:
         cfg.max_steps    = 0;
         cfg.trace_mode   = VRT_TRACE_AUTO;
         check(vrt_create(&cfg, &ctx_));
+        check(vrt_kernel_time_sampling(ctx_, 0));  // a game loop does not read kernel times: no events around the launches
         previous_frame_end = FrameToken{ctx_};
         resize(width_, height_);
     }

@@ -79,6 +79,8 @@ impl GraphicsCore {
         };
         let mut ctx = null_mut();
         check(unsafe { vrt_sys::vrt_create(&cfg, &mut ctx) });
+        // a game loop does not read kernel times: no events around the launches
+        check(unsafe { vrt_sys::vrt_kernel_time_sampling(ctx, 0) });
         GraphicsCore {
             ctx,
             settings,

@@ -13,12 +13,25 @@ frame of its own camera pose (weak scaling); the BGRA8 framebuffers are gathered
 frame dealt to the ranks in interleaved 16-row strips (strong scaling), gathered and put back
 in row order on rank 0 by the library's copy kernel.
 
-Prints ONE JSON line on rank 0.  `roofline.achieved` = algorithmic bytes per launch /
-mean HIP-event duration of the trace kernel, where algorithmic bytes are what the
-reference's traversal reads and writes for the same frame: one voxel byte per loop
-iteration per ray (u8 layout, no distance image) + 4 bytes of BGRA8 per ray.
+Prints ONE JSON line on rank 0.
+
+`roofline` names the roof that binds the kernel of the timed region.  The skip kernel reads 22 MB per
+frame and is bound by vector-instruction issue: `achieved` = wave64 vector instructions per launch (the
+committed counter pass of this command, profiles/traffic.json) / mean HIP-event duration of the kernel
+measured in this run; `peak` = the chip's issue rate for independent v_fma_f32 with eight wavefronts per
+SIMD, measured in this run by libvrt_selftest.so.  `roofline.hbm` is the memory side of the same launch:
+counter bytes (FETCH_SIZE corrected + WRITE_SIZE) / the same duration against the 8 TB/s data-sheet peak.
+`roofline.reference_equivalent_GBs` is the rate at which the REFERENCE's loop would have to move bytes to
+produce the frame in that time (one voxel byte per loop iteration per ray + 4 bytes of BGRA8 per ray); the
+skip kernel does not move those bytes, so this is a speed-up figure, not a bandwidth.
+`roofline_literal` is the literal kernel (one voxel load per reference iteration) on the same frame: the
+kernel whose HBM-side work IS the algorithmic byte count, priced against the HBM peak.
 `cpu_baseline` = the CPU oracle (a C restatement of the reference shader, not the
 reference itself) timed on a bounded sample of the same frame on this host's cores.
+
+Started as plain `python bench.py --gpus N` with N > 1 (no WORLD_SIZE in the environment), this process
+touches no GPU: it runs `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child,
+relays the child's JSON line and exits with its code.
 """
 import argparse
 import json
@@ -70,6 +83,45 @@ def cpu_baseline(core, cam, steps_plane):
             "matches_gpu_steps": bool(ok)}
 
 
+def valu_issue_rates(device):
+    """Issue rate of wave64 vector instructions on this GPU, measured now by libvrt_selftest.so (long streams of
+    independent instructions on every SIMD of every compute unit)."""
+    import ctypes as C
+    lib = C.CDLL(os.path.join(ROOT, "raytracing_amd", "libvrt_selftest.so"))
+    lib.vrt_selftest_valu_rate.restype = C.c_int
+    lib.vrt_selftest_valu_rate.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    res = {}
+    for key, kind, waves in (("fma_8_waves", 0, 8), ("trace_mix_8_waves", 2, 8), ("fma_1_wave", 0, 1)):
+        out = (C.c_double * 4)()
+        rc = lib.vrt_selftest_valu_rate(device, kind, waves, out)
+        if rc != 0:
+            raise RuntimeError(f"vrt_selftest_valu_rate failed with HIP error {rc}")
+        res[key] = {"ginstr_s": out[0] / 1e9, "shader_ghz": out[1], "cycles_per_instr_per_simd": out[2]}
+    return res
+
+
+def literal_roofline(device, cam, wmin, alg_bytes, skip_frame):
+    """The literal kernel on the same frame (a second context with its own copy of the world): one voxel byte
+    per reference iteration + 4 bytes per ray over the mean HIP-event duration of 16 launches."""
+    with GraphicsCore(width=W, height=H, device=device, grid_n=N_GRID, voxel_format=VOXEL_PACKED_U8,
+                      trace_mode=TRACE_LITERAL) as lit:
+        lit.generate_window(wmin)
+        frame = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+        for _ in range(2):
+            lit.trace_device(cam, W, H, 0, H, {"bgra8": frame.data_ptr()})
+        lit.sync()
+        lit.kernel_time_sampling(1)
+        lit.kernel_time_reset()
+        for _ in range(16):
+            lit.trace_device(cam, W, H, 0, H, {"bgra8": frame.data_ptr()})
+        ms, n = lit.kernel_time()
+        same = bool(torch.equal(frame, skip_frame))
+    s = ms / 1e3 / n
+    return {"bound": "hbm", "achieved": alg_bytes / s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": alg_bytes / s / 1e9 / HBM_PEAK_GBS, "kernel": "literal", "kernel_ms": s * 1e3, "timed_launches": int(n),
+            "algorithmic_bytes_per_launch": alg_bytes, "frame_equals_skip_kernel_frame": same}
+
+
 def copy_bandwidth_gbs(nbytes=1 << 30, reps=10):
     """Device-to-device copy rate of this GPU (bytes read + bytes written per second), the practical
     ceiling beside the 8 TB/s data-sheet figure."""
@@ -84,6 +136,28 @@ def copy_bandwidth_gbs(nbytes=1 << 30, reps=10):
     e1.record()
     torch.cuda.synchronize()
     return 2.0 * nbytes * reps / (e0.elapsed_time(e1) / 1e3) / 1e9
+
+
+def launch_ranks(n):
+    """Plain `python bench.py --gpus N`, N > 1: one rank per GPU through torch.distributed.run, as a CHILD
+    process (this process has made no HIP call and makes none; a process that has touched the GPU must not
+    be replaced by another program).  Rank 0's JSON line is relayed on stdout, everything else on stderr;
+    returns the child's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # RCCL / device-memory sharing between ranks needs dmabuf IPC here
+    env.setdefault("OMP_NUM_THREADS", "4")
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    for line in child.stdout:
+        (sys.stdout if line.lstrip().startswith('{"metric"') else sys.stderr).write(line)
+        sys.stdout.flush()
+    return child.wait()
 
 
 class stdout_to_stderr:
@@ -108,6 +182,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--mode", choices=["auto", "skip", "literal"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="start the ranks, let them find each other over gloo, print {n_gpus, ranks_seen} and stop: "
+                         "checks the launch path on a host without GPUs")
+    ap.add_argument("--no-literal", action="store_true", help="skip the literal kernel's line (roofline_literal)")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the RCCL gather path with a single rank as well (rehearsal of the N > 1 code on one GPU)")
     ap.add_argument("--shard", choices=["poses", "strips"], default="poses",
@@ -117,19 +195,38 @@ def main():
                     help="frames per gather (pose sharding, N > 1): each rank fills a buffer of this many frames and hands it "
                          "to one gather, which overlaps the tracing of the next buffer; every frame still reaches rank 0 "
                          "inside the timed region.  1 = one gather per frame")
-    ap.add_argument("--time-every", type=int, default=8,
-                    help="bracket one frame in this many with HIP events (the events themselves cost stream time)")
+    ap.add_argument("--time-every", type=int, default=0,
+                    help="bracket one frame in this many of the timed region with HIP events as well (0 = none: the two "
+                         "events cost about 7 us of stream time per launch; the kernel's duration is measured on "
+                         "--probe launches right after the timed region instead)")
+    ap.add_argument("--probe", type=int, default=32,
+                    help="launches of the same frame, each bracketed by HIP events on the context's stream, from which "
+                         "the kernel's mean duration is taken (at least 16)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo: rehearsal of the multi-rank path on hosts without one GPU per rank "
                          "(frames are gathered through host memory; not a measurement)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU "
+                         "(or plain `python bench.py --gpus N`, which starts them itself)")
+    if args.launch_check:
+        # the launch path alone (no GPU work): every rank joins a gloo group, rank 0 reports how many it saw
+        if world > 1:
+            dist.init_process_group("gloo")
+        seen = torch.ones(1, dtype=torch.int64)
+        if world > 1:
+            dist.all_reduce(seen)
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"metric": "launch check", "n_gpus": world, "ranks_seen": int(seen.item()),
+                              "steps": args.steps, "warmup": args.warmup}), flush=True)
+        return
     if args.backend == "gloo":
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
@@ -266,14 +363,27 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    core.kernel_time_sampling(max(1, min(args.time_every, args.steps)))
+    core.kernel_time_sampling(max(0, min(args.time_every, args.steps)))
     core.kernel_time_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
+    region_ms, region_launches = core.kernel_time()
+
+    # the kernel alone: the same launch again, every one bracketed by two HIP events on the context's stream
+    probe = max(16, args.probe)
+    core.kernel_time_sampling(1)
+    core.kernel_time_reset()
+    for _ in range(probe):
+        if strips:
+            core.trace_strips_device(cam, W, H, STRIP_H, rank, world, {"bgra8": packed[0].data_ptr()})
+        else:
+            core.trace_device(cam, W, H, 0, H, {"bgra8": frames[0].data_ptr()})
+    core.sync()
     kern_ms, launches = core.kernel_time()
+    core.kernel_time_sampling(0)
 
     kern_max_s = kern_ms / 1e3 / max(launches, 1)
     if multi:
@@ -284,22 +394,42 @@ def main():
     if rank == 0:
         rays = W * H * args.steps * (1 if strips else world)
         kern_s = kern_ms / 1e3 / max(launches, 1)
-        achieved = alg_bytes / kern_s / 1e9
-        traffic = None
-        limiter = None
+        name = core.last_kernel_name()
+        ref_equiv_gbs = alg_bytes / kern_s / 1e9
+        traffic = valu = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf) and not strips:   # the committed counters describe whole-frame launches
             try:
                 prof = json.load(open(tf))
-                traffic = prof.get(core.last_kernel_name())
-                valu = prof.get(core.last_kernel_name() + "_valu_instructions")
-                if valu:
-                    # what actually bounds the kernel: one wave64 VALU instruction occupies a SIMD for 4 cycles;
-                    # 256 CUs x 4 SIMDs at 2.4 GHz (instruction count from the committed PMC pass, time measured now)
-                    limiter = {"kind": "valu_issue", "valu_instructions_per_launch": valu,
-                               "frac_of_kernel_time": valu * 4 / 1024 / (kern_s * 2.4e9)}
+                traffic = prof.get(name)
+                valu = prof.get(name + "_valu_instructions")
             except Exception:
-                traffic = None
+                traffic = valu = None
+        hbm = {"achieved": traffic / kern_s / 1e9 if traffic else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": traffic / kern_s / 1e9 / HBM_PEAK_GBS if traffic else None,
+               "bytes": "FETCH_SIZE x 2 (gfx950 tallies 128-B fills as 64 B) + WRITE_SIZE per launch, profiles/traffic.json"}
+        common = {"traffic": traffic, "kernel_ms": kern_s * 1e3, "timed_launches": int(launches),
+                  "timed_how": f"{int(launches)} launches of the same frame right after the timed region, each bracketed by "
+                               "two HIP events on the context's stream",
+                  "kernel_mrays_s": launch_rays / kern_s / 1e6, "mean_steps_per_ray": sum_steps / launch_rays,
+                  "algorithmic_bytes_per_launch": alg_bytes, "reference_equivalent_GBs": ref_equiv_gbs}
+        if region_launches:
+            common["region_sampled_kernel_ms"] = region_ms / region_launches
+        if name == "literal":
+            # one voxel load per reference iteration: the algorithmic bytes are this kernel's own work
+            roofline = {"bound": "hbm", "achieved": ref_equiv_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ref_equiv_gbs / HBM_PEAK_GBS, **common}
+        else:
+            issue = valu_issue_rates(local_rank)
+            roofline = {"bound": "valu_issue",
+                        "achieved": valu / kern_s / 1e9 if valu else None, "peak": issue["fma_8_waves"]["ginstr_s"],
+                        "unit": "G wave64 vector instructions/s",
+                        "frac": valu / kern_s / 1e9 / issue["fma_8_waves"]["ginstr_s"] if valu else None,
+                        "valu_instructions_per_launch": valu,
+                        "valu_count_from": "SQ_INSTS_VALU per launch, rocprofv3 --pmc pass of this command (profiles/traffic.json)",
+                        "peak_measured": issue, "hbm": hbm, **common}
+        copy_gbs = copy_bandwidth_gbs()
+        roofline["measured_copy_GBs"] = copy_gbs
         line = {
             "metric": "primary Mrays/s at 1920x1080 on 1024^3 grid",
             "value": rays / dt / 1e6,
@@ -320,18 +450,12 @@ def main():
                                       "BGRA8 gather + row reorder on rank 0" if strips else
                                       "world replicated per GPU, one pose per GPU, BGRA8 gather to rank 0"
                                       + (f" ({G} frames per gather)" if multi else "")),
-                       "kernel": core.last_kernel_name(), "grid_n": N_GRID, "width": W, "height": H,
+                       "kernel": name, "grid_n": N_GRID, "width": W, "height": H,
                        "world_build_s": round(build_s, 3)},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_s * 1e3,
-                         "timed_launches": int(launches),
-                         "kernel_mrays_s": launch_rays / kern_s / 1e6, "mean_steps_per_ray": sum_steps / launch_rays},
+            "roofline": roofline,
         }
-        if limiter:
-            line["roofline"]["limiter"] = limiter
-        copy_gbs = copy_bandwidth_gbs()
-        line["roofline"]["measured_copy"] = {"GB/s": copy_gbs, "frac": achieved / copy_gbs}
+        if world == 1 and name == "skip" and not args.no_literal:
+            line["roofline_literal"] = literal_roofline(local_rank, cam, wmin, alg_bytes, frames[0])
         # the frame just timed against the frozen oracle output for this pose (tests/golden/fullsize)
         gold = os.path.join(ROOT, "tests", "golden", "fullsize", "headline_1080p_n1024.json")
         if os.path.exists(gold) and core.last_kernel_name() in ("skip", "literal"):

@@ -38,6 +38,31 @@ int fail(int code, const char *fmt, ...)
 
 constexpr int kEventRing = 64;
 
+constexpr uint32_t kSchedRows = 256;  // = SCHED_MAX_ROWS of the kernels
+constexpr size_t   kSchedHead = 2 + 2 * kSchedRows;
+
+// Device memory a trace launch needs beyond the world and the caller's planes, and what the host knows
+// about its contents:
+//   tables  ncx[max_dim] | ncy[max_dim + 1] | sin2[3][grid_n + 8]        (TraceParams::ncx, ncy, sin2)
+//   sched   start[2] | row_longest[2][256] | cost[2][sched_capacity]      (vrt::RowSched)
+// A context owns one (allocated in vrt_create).
+struct Scratch {
+    float    *tables        = nullptr;
+    uint32_t  max_dim       = 0;         // frame width / height the tables have room for
+    uint32_t  sin_cap       = 0;         // entries per axis the sine table has room for
+    uint32_t *sched         = nullptr;
+    uint32_t  sched_capacity = 0;        // wavefronts per launch the dispatch-order feedback covers
+    // contents
+    uint32_t  tab_w = 0, tab_h = 0, tab_sin_len = 0;  // frame / grid the tables were filled for (0: none)
+    int32_t   tab_base[3]   = {0, 0, 0};
+    uint32_t  sched_gen     = 0;             // generation of the last skip launch, 1..4095
+    uint32_t  sched_same    = 0;             // consecutive launches of this shape before the next one
+    uint64_t  sched_sig[5]  = {0, 0, 0, 0, 0};  // shape of the last launch; [0] == 0: none
+
+    size_t table_floats() const { return (size_t)2 * max_dim + 1 + 3 * (size_t)sin_cap; }
+    size_t sched_bytes() const { return (kSchedHead + 2 * (size_t)sched_capacity) * sizeof(uint32_t); }
+};
+
 }  // namespace
 
 struct vrt_ctx {
@@ -57,10 +82,9 @@ struct vrt_ctx {
     uint4      *d_cells      = nullptr;  // (n/4)^3 records: occupancy mask + octant distances
     uint16_t   *d_tops       = nullptr;  // column-top pyramid scratch, 2 * (n/4)^2
     uint4      *d_pyr        = nullptr;  // (n/4)^3 x 16 B: column-top pyramid at voxel precision
-    // per-frame tables (TraceParams::ncx, ncy, sin2): ncx[16384] | ncy[16385] | sin2[3][grid_n + 8]
-    float      *d_tables     = nullptr;
-    uint32_t    tab_w = 0, tab_h = 0;    // frame the tables were filled for (0: none)
-    int32_t     tab_base[3]  = {0, 0, 0};
+    uint8_t    *d_build      = nullptr;  // 11 x (n/4)^3 B: intermediates of the octant distance passes, kept between builds
+    Scratch     own;                     // per-frame tables + dispatch-order slots of this context
+    uint64_t    serial       = 0;        // distinguishes contexts in the dispatch-order history of a shared scratch
     int         pyr_offcy    = -1;       // vertical window offset (cells) the pyramid entries were built for
     bool        skip_valid   = false;
     uint32_t   *d_flag       = nullptr;
@@ -72,11 +96,6 @@ struct vrt_ctx {
     uint32_t    knob_tile_log2h = 2;
     bool        knob_no_row_order = false, knob_sched_debug = false;
     int32_t     knob_row_block0 = -1;
-    // dispatch-order feedback of the skip kernels (vrt::RowSched)
-    uint32_t   *d_sched      = nullptr;       // start[2] | row_longest[2][256] | cost[2][kSchedCapacity]
-    uint32_t    sched_gen    = 0;             // generation of the last skip launch, 1..4095
-    uint32_t    sched_same   = 0;             // consecutive launches of this shape before the next one
-    uint64_t    sched_sig[4] = {0, 0, 0, 0};  // shape of the last launch; [0] == 0: none
     // staging for host-resident outputs
     void       *d_stage      = nullptr;
     size_t      stage_bytes  = 0;
@@ -108,25 +127,22 @@ int drain_events(vrt_ctx *c)
     return VRT_OK;
 }
 
-// offcy: rem_euclid(lower_y, n) / 4 of the window the next trace uses
+// Brings the skip structure up to date with the voxel image.  offcy: rem_euclid(lower_y, n) / 4 of the window
+// the next trace uses, or -1 when no camera is known yet (the column-top pyramid, whose entries count levels
+// from the bottom of the window, is then left to the next trace).  Buffers are allocated on the first call
+// and kept; everything else is launches on the context's stream.
 int ensure_skip_structure(vrt_ctx *c, int offcy)
 {
     if (!c->skip_valid) {
         if (!c->d_cells) HIP_TRY(hipMalloc(&c->d_cells, cells(c) * sizeof(uint4)));
         if (!c->d_tops) HIP_TRY(hipMalloc(&c->d_tops, 2 * (size_t)(c->n / 4) * (c->n / 4) * sizeof(uint16_t)));
         if (!c->d_pyr) HIP_TRY(hipMalloc(&c->d_pyr, cells(c) * sizeof(uint4)));
-        // scratch for the separable distance passes: released again, the build is not a hot path
-        uint8_t *tmp = nullptr;
-        HIP_TRY(hipMalloc(&tmp, 11 * cells(c)));
-        hipError_t e = vrt::launch_build_cells(c->d_block, c->voxel_bytes, (int)c->n, c->d_cells, tmp, c->stream);
-        hipError_t e2 = hipStreamSynchronize(c->stream);
-        (void)hipFree(tmp);
-        HIP_TRY(e);
-        HIP_TRY(e2);
+        if (!c->d_build) HIP_TRY(hipMalloc(&c->d_build, 11 * cells(c)));  // the separable distance passes' intermediates
+        HIP_TRY(vrt::launch_build_cells(c->d_block, c->voxel_bytes, (int)c->n, c->d_cells, c->d_build, c->stream));
         c->skip_valid = true;
         c->pyr_offcy = -1;
     }
-    if (c->pyr_offcy != offcy) {
+    if (offcy >= 0 && c->pyr_offcy != offcy) {
         HIP_TRY(vrt::launch_build_voxel_pyramid(c->d_cells, (int)c->n / 4, offcy, c->d_tops, c->d_pyr, c->stream));
         c->pyr_offcy = offcy;
     }
@@ -144,8 +160,6 @@ int window_offcy(const vrt_ctx *c, float y)
 }
 
 struct Plane { size_t off, bytes; void *host; };
-
-constexpr uint32_t kSchedRows = 256;  // = SCHED_MAX_ROWS of the kernels
 
 // Packed row (of this launch) on which the central ray is horizontal: the rows with the longest rays
 // lie just under it, so a launch is only comparable with the previous one if it has not moved much.
@@ -170,67 +184,68 @@ uint32_t horizon_packed_row(const float *m, uint32_t w, uint32_t h, const vrt::R
     return q < rows.rows ? q : rows.rows - 1;
 }
 
-constexpr uint32_t kSchedCapacity = 262144;  // wavefronts per launch the feedback covers (1080p: 32640, 4K: 129600)
-constexpr size_t kSchedHead = 2 + 2 * kSchedRows;
-constexpr size_t kSchedBytes = (kSchedHead + 2 * (size_t)kSchedCapacity) * sizeof(uint32_t);
+constexpr uint32_t kSchedCapacity = 262144;  // wavefronts per launch a context's own feedback covers (1080p: 32640, 4K: 129600)
 
-// Fills p.sched for a skip-kernel launch (kind 1: primary, 2: primary + secondary).  The start row
-// planned by the previous launch from the times of the launch before it is used when both had this
-// launch's kernel, frame, rows and (to a workgroup row) horizon; either way this launch measures.
-int attach_row_sched(vrt_ctx *c, vrt::TraceParams &p, uint32_t kind)
+// Fills p.sched for a skip-kernel launch (kind 1: primary, 2: primary + secondary) from the slots in S.  The
+// start row planned by the previous launch from the times of the launch before it is used when both had this
+// launch's context, kernel, frame, rows and (to a workgroup row) horizon; either way this launch measures.
+int attach_row_sched(vrt_ctx *c, Scratch &S, vrt::TraceParams &p, uint32_t kind)
 {
     p.sched = vrt::RowSched{};
     p.sched.fixed_start = -1;
-    if (c->knob_row_block0 >= 0) { p.sched.fixed_start = c->knob_row_block0; c->sched_sig[0] = 0; return VRT_OK; }
+    if (c->knob_row_block0 >= 0) { p.sched.fixed_start = c->knob_row_block0; S.sched_sig[0] = 0; return VRT_OK; }
     const uint32_t block_h = 4u << p.tile_log2h;
     const uint32_t grid_y = (p.rows.rows + block_h - 1) / block_h;
     const uint32_t grid_x = (p.w + (64u >> p.tile_log2h) - 1) / (64u >> p.tile_log2h);
-    if (!c->d_sched || grid_y == 0 || grid_y > kSchedRows || (uint64_t)grid_x * grid_y * 4 > kSchedCapacity || c->knob_no_row_order) {
-        c->sched_sig[0] = 0;
+    if (!S.sched || grid_y == 0 || grid_y > kSchedRows || (uint64_t)grid_x * grid_y * 4 > S.sched_capacity || c->knob_no_row_order) {
+        S.sched_sig[0] = 0;
         return VRT_OK;
     }
-    const uint64_t sig[4] = {
+    const uint64_t sig[5] = {
         ((uint64_t)kind << 56) | ((uint64_t)p.tile_log2h << 48) | ((uint64_t)p.w << 24) | (uint64_t)p.h,
         ((uint64_t)p.rows.y0 << 32) | (uint64_t)p.rows.rows,
         ((uint64_t)p.rows.strip_h << 40) | ((uint64_t)p.rows.part << 20) | (uint64_t)p.rows.parts,
-        (uint64_t)(horizon_packed_row(p.m, p.w, p.h, p.rows) / block_h)};
-    if (c->knob_sched_debug && c->sched_gen > 0) {  // diagnostic: what the last launch measured
-        std::vector<uint32_t> hbuf(kSchedHead + 2 * (size_t)kSchedCapacity);
+        (uint64_t)(horizon_packed_row(p.m, p.w, p.h, p.rows) / block_h),
+        c->serial};
+    if (c->knob_sched_debug && S.sched_gen > 0 && &S == &c->own) {  // diagnostic: what the last launch measured
+        std::vector<uint32_t> hbuf(kSchedHead + 2 * (size_t)S.sched_capacity);
         HIP_TRY(hipStreamSynchronize(c->stream));
-        HIP_TRY(hipMemcpy(hbuf.data(), c->d_sched, kSchedBytes, hipMemcpyDeviceToHost));
-        const uint32_t g = c->sched_gen;
+        HIP_TRY(hipMemcpy(hbuf.data(), S.sched, S.sched_bytes(), hipMemcpyDeviceToHost));
+        const uint32_t g = S.sched_gen;
         std::fprintf(stderr, "[sched] gen %u start[0]=%u/%u start[1]=%u/%u rows:", g, hbuf[0] >> 16, hbuf[0] & 0xffff,
                      hbuf[1] >> 16, hbuf[1] & 0xffff);
         for (uint32_t r = 0; r < grid_y; ++r) {
             uint32_t m = 0;
             for (uint32_t x = 0; x < grid_x * 4; ++x) {
-                const uint32_t v = hbuf[kSchedHead + (size_t)(g & 1) * kSchedCapacity + r * grid_x * 4 + x];
+                const uint32_t v = hbuf[kSchedHead + (size_t)(g & 1) * S.sched_capacity + r * grid_x * 4 + x];
                 if ((v >> 20) == g) m = std::max(m, v & 0xfffffu);
             }
             std::fprintf(stderr, " %u", m);
         }
         std::fprintf(stderr, "\n");
     }
-    c->sched_same = std::memcmp(sig, c->sched_sig, sizeof sig) == 0 ? c->sched_same + 1 : 0;
-    if (c->sched_gen >= 4095u) {  // the tags are 12 bits wide: start over with clean slots
-        HIP_TRY(hipMemsetAsync(c->d_sched, 0, kSchedBytes, c->stream));
-        c->sched_gen = 0;
-        c->sched_same = 0;
+    S.sched_same = std::memcmp(sig, S.sched_sig, sizeof sig) == 0 ? S.sched_same + 1 : 0;
+    if (S.sched_gen >= 4095u) {  // the tags are 12 bits wide: start over with clean slots
+        HIP_TRY(hipMemsetAsync(S.sched, 0, S.sched_bytes(), c->stream));
+        S.sched_gen = 0;
+        S.sched_same = 0;
     }
-    c->sched_gen += 1;
-    p.sched.start = c->d_sched;
-    p.sched.row_longest = c->d_sched + 2;
-    p.sched.cost = c->d_sched + kSchedHead;
-    p.sched.capacity = kSchedCapacity;
-    p.sched.generation = c->sched_gen;
-    p.sched.use_order = c->sched_same >= 3 ? 1u : 0u;
-    std::memcpy(c->sched_sig, sig, sizeof sig);
+    S.sched_gen += 1;
+    p.sched.start = S.sched;
+    p.sched.row_longest = S.sched + 2;
+    p.sched.cost = S.sched + kSchedHead;
+    p.sched.capacity = S.sched_capacity;
+    p.sched.generation = S.sched_gen;
+    p.sched.use_order = S.sched_same >= 3 ? 1u : 0u;
+    std::memcpy(S.sched_sig, sig, sizeof sig);
     return VRT_OK;
 }
 
 // argument checks, kernel choice and the parameter block shared by every trace entry point
-int prepare_trace(vrt_ctx *c, const float *cam, uint32_t w, uint32_t h, const vrt::RowMap &rows, bool need_skip,
-                  vrt::TraceParams &p, bool &use_skip)
+// (S: the scratch whose tables the launch reads; may_build: the skip structure may be (re)built here, which
+// allocates on its first use)
+int prepare_trace(vrt_ctx *c, Scratch &S, bool may_build, const float *cam, uint32_t w, uint32_t h, const vrt::RowMap &rows,
+                  bool need_skip, vrt::TraceParams &p, bool &use_skip)
 {
     if (!c || !cam) return fail(VRT_E_INVALID_ARG, "null argument");
     if (w == 0 || h == 0 || w > 16384 || h > 16384) return fail(VRT_E_INVALID_ARG, "frame size out of range");
@@ -254,7 +269,10 @@ int prepare_trace(vrt_ctx *c, const float *cam, uint32_t w, uint32_t h, const vr
         use_skip = true;
     }
     if (use_skip) {
-        int rc = ensure_skip_structure(c, window_offcy(c, cam[13]));
+        if (!may_build && (!c->skip_valid || !c->d_pyr))
+            return fail(VRT_E_UNSUPPORTED, "the skip structure is not built: call vrt_reset_distance_field (or vrt_trace once) "
+                                           "after the last change to the world");
+        int rc = ensure_skip_structure(c, window_offcy(c, cam[13]));  // at most the pyramid's relevelling launches from here
         if (rc != VRT_OK) return rc;
     }
 
@@ -280,15 +298,16 @@ int prepare_trace(vrt_ctx *c, const float *cam, uint32_t w, uint32_t h, const vr
     p.dist = c->dist_nonzero ? c->d_dist : nullptr;
     p.cells = c->d_cells; p.nc = (int)c->n / 4; p.pyr = c->d_pyr;
     {   // per-frame tables: refilled (one small launch) when the frame shape or the window position changes
-        constexpr uint32_t kMaxDim = 16384;
         const uint32_t sin_len = c->n + 8;
-        if (!c->d_tables) HIP_TRY(hipMalloc(&c->d_tables, ((size_t)2 * kMaxDim + 1 + 3 * (size_t)sin_len) * sizeof(float)));
-        float *ncx = c->d_tables, *ncy = ncx + kMaxDim, *sin2 = ncy + kMaxDim + 1;
+        if (w > S.max_dim || h > S.max_dim || sin_len > S.sin_cap || !S.tables)
+            return fail(VRT_E_INVALID_ARG, "frame %u x %u or grid %u beyond what the scratch tables hold (%u, %u)", w, h, c->n,
+                        S.max_dim, S.sin_cap > 8 ? S.sin_cap - 8 : 0);
+        float *ncx = S.tables, *ncy = ncx + S.max_dim, *sin2 = ncy + S.max_dim + 1;
         const int32_t base[3] = {p.lo[0] - 4, p.lo[1] - 4, p.lo[2] - 4};
-        if (c->tab_w != w || c->tab_h != h || std::memcmp(base, c->tab_base, sizeof base) != 0) {
+        if (S.tab_w != w || S.tab_h != h || S.tab_sin_len != sin_len || std::memcmp(base, S.tab_base, sizeof base) != 0) {
             HIP_TRY(vrt::launch_frame_tables(ncx, ncy, sin2, w, h, p.ncy_off, base, sin_len, c->stream));
-            c->tab_w = w; c->tab_h = h;
-            std::memcpy(c->tab_base, base, sizeof base);
+            S.tab_w = w; S.tab_h = h; S.tab_sin_len = sin_len;
+            std::memcpy(S.tab_base, base, sizeof base);
         }
         p.ncx = ncx; p.ncy = ncy; p.sin2 = sin2; p.sin_len = sin_len;
         std::memcpy(p.sin_base, base, sizeof base);
@@ -313,7 +332,7 @@ int do_trace(vrt_ctx *c, const float *cam, uint32_t w, uint32_t h, const vrt::Ro
     if (out->memory != VRT_MEM_HOST && out->memory != VRT_MEM_DEVICE) return fail(VRT_E_INVALID_ARG, "bad outputs.memory");
     vrt::TraceParams p;
     bool use_skip = false;
-    { int rc = prepare_trace(c, cam, w, h, rows, false, p, use_skip); if (rc != VRT_OK) return rc; }
+    { int rc = prepare_trace(c, c->own, true, cam, w, h, rows, false, p, use_skip); if (rc != VRT_OK) return rc; }
 
     const size_t px = (size_t)rows.rows * w;
     Plane planes[7] = {{0, out->bgra8 ? px * 4 : 0, out->bgra8},       {0, out->voxel ? px * 12 : 0, out->voxel},
@@ -336,7 +355,7 @@ int do_trace(vrt_ctx *c, const float *cam, uint32_t w, uint32_t h, const vrt::Ro
     if (timed && c->ev_pending == kEventRing) { int rc = drain_events(c); if (rc != VRT_OK) return rc; }
     const int e = c->ev_pending;
     if (timed) HIP_TRY(hipEventRecord(c->ev0[e], c->stream));
-    if (use_skip) { int rc = attach_row_sched(c, p, 1); if (rc != VRT_OK) return rc; }
+    if (use_skip) { int rc = attach_row_sched(c, c->own, p, 1); if (rc != VRT_OK) return rc; }
     if (use_skip) { HIP_TRY(vrt::launch_trace_skip(p, c->voxel_bytes, c->stream)); c->last_kernel = "skip"; }
     else          { HIP_TRY(vrt::launch_trace_literal(p, c->voxel_bytes, c->stream)); c->last_kernel = "literal"; }
     if (timed) { HIP_TRY(hipEventRecord(c->ev1[e], c->stream)); c->ev_pending = e + 1; }
@@ -397,8 +416,13 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out)
     TRY_OR_BAIL(hipMalloc(&c->d_block, texels(c) * (size_t)c->voxel_bytes));
     TRY_OR_BAIL(hipMalloc(&c->d_flag, sizeof(uint32_t)));
     {
-        TRY_OR_BAIL(hipMalloc(&c->d_sched, kSchedBytes));
-        TRY_OR_BAIL(hipMemsetAsync(c->d_sched, 0, kSchedBytes, c->stream));
+        static uint64_t next_serial = 0;
+        c->serial = ++next_serial;
+        Scratch &S = c->own;
+        S.max_dim = 16384; S.sin_cap = c->n + 8; S.sched_capacity = kSchedCapacity;
+        TRY_OR_BAIL(hipMalloc(&S.tables, S.table_floats() * sizeof(float)));
+        TRY_OR_BAIL(hipMalloc(&S.sched, S.sched_bytes()));
+        TRY_OR_BAIL(hipMemsetAsync(S.sched, 0, S.sched_bytes(), c->stream));
     }
 #undef TRY_OR_BAIL
     *out = c;
@@ -414,7 +438,7 @@ int vrt_destroy(vrt_ctx *c)
         if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]);
         if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]);
     }
-    void *bufs[] = {c->d_block, c->d_dist, c->d_cells, c->d_tops, c->d_pyr, c->d_tables, c->d_flag, c->d_sched, c->d_stage};
+    void *bufs[] = {c->d_block, c->d_dist, c->d_cells, c->d_tops, c->d_pyr, c->d_build, c->own.tables, c->d_flag, c->own.sched, c->d_stage};
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -482,8 +506,8 @@ int vrt_reset_distance_field(vrt_ctx *c)
     if (c->d_dist) HIP_TRY(hipMemsetAsync(c->d_dist, 0, texels(c) * sizeof(uint16_t), c->stream));
     c->dist_nonzero = false;
     if (c->have_world && c->trace_mode != VRT_TRACE_LITERAL) {
-        c->skip_valid = false;
-        return ensure_skip_structure(c, c->pyr_offcy >= 0 ? c->pyr_offcy : 0);
+        // (the pyramid is levelled by the next trace, which knows the camera's window)
+        return ensure_skip_structure(c, -1);
     }
     return VRT_OK;
 }
@@ -505,7 +529,7 @@ int vrt_trace_secondary(vrt_ctx *c, const float cam[16], uint32_t w, uint32_t h,
     vrt::RowMap rows{y0, y1 - y0, 0, 0, 1};
     vrt::TraceParams p;
     bool use_skip = false;
-    { int rc = prepare_trace(c, cam, w, h, rows, true, p, use_skip); if (rc != VRT_OK) return rc; }
+    { int rc = prepare_trace(c, c->own, true, cam, w, h, rows, true, p, use_skip); if (rc != VRT_OK) return rc; }
     const size_t px = (size_t)rows.rows * w;
     Plane planes[3] = {{0, out->shadow ? px : 0, out->shadow}, {0, out->ao ? px : 0, out->ao},
                        {0, out->sec_steps ? px * 4 : 0, out->sec_steps}};
@@ -522,7 +546,7 @@ int vrt_trace_secondary(vrt_ctx *c, const float cam[16], uint32_t w, uint32_t h,
     if (timed && c->ev_pending == kEventRing) { int rc = drain_events(c); if (rc != VRT_OK) return rc; }
     const int e = c->ev_pending;
     if (timed) HIP_TRY(hipEventRecord(c->ev0[e], c->stream));
-    { int rc = attach_row_sched(c, p, 2); if (rc != VRT_OK) return rc; }
+    { int rc = attach_row_sched(c, c->own, p, 2); if (rc != VRT_OK) return rc; }
     HIP_TRY(vrt::launch_trace_secondary(p, c->voxel_bytes, (uint8_t *)dev[0], (uint8_t *)dev[1], (uint32_t *)dev[2], c->stream));
     c->last_kernel = "secondary";
     if (timed) { HIP_TRY(hipEventRecord(c->ev1[e], c->stream)); c->ev_pending = e + 1; }
@@ -538,9 +562,9 @@ uint32_t vrt_strip_rows(uint32_t h, uint32_t strip_h, uint32_t part, uint32_t pa
 {
     if (strip_h == 0 || parts == 0 || part >= parts) return 0;
     uint32_t rows = 0;
-    for (uint32_t s = part; (uint64_t)s * strip_h < h; s += parts) {
-        const uint32_t a = s * strip_h, b = a + strip_h < h ? a + strip_h : h;
-        rows += b - a;
+    for (uint64_t s = part; s * strip_h < h; s += parts) {
+        const uint64_t a = s * strip_h, b = a + strip_h < h ? a + strip_h : h;
+        rows += (uint32_t)(b - a);
     }
     return rows;
 }
@@ -604,6 +628,7 @@ int vrt_sync(vrt_ctx *c)
 int vrt_download_world(vrt_ctx *c, void *block_out, uint32_t memory)
 {
     if (!c || !block_out) return fail(VRT_E_INVALID_ARG, "null argument");
+    if (memory != VRT_MEM_HOST && memory != VRT_MEM_DEVICE) return fail(VRT_E_INVALID_ARG, "bad memory kind");
     if (!c->have_world) return fail(VRT_E_NO_WORLD, "no world uploaded or generated");
     HIP_TRY(hipSetDevice(c->device));
     const hipMemcpyKind kind = memory == VRT_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;

@@ -1,6 +1,7 @@
 // vrt_selftest.hip -- exhaustive checks of device arithmetic that the kernels rely on, in a small library
 // of its own (libvrt_selftest.so) that only the tests load.
 #include "vrt_device.h"
+#include "vrt_kernels.h"
 
 namespace {
 
@@ -46,5 +47,176 @@ extern "C" int vrt_selftest_recip(int device, unsigned long long out[3])
     if (e == hipSuccess) e = hipMemcpy(out, d, sizeof init, hipMemcpyDeviceToHost);
     (void)hipFree(d);
     if (e == hipSuccess) out[2] &= 0xffffffffull;
+    return (int)e;
+}
+
+// ---------------------------------------------------------------------------
+// VALU issue rate of the chip: what bounds a kernel that is neither memory nor matrix bound.
+// ---------------------------------------------------------------------------
+namespace {
+
+constexpr int kRateUnroll = 64;  // instructions per loop iteration (16 independent chains x 4)
+
+// KIND 0: v_fma_f32   1: v_add_u32   2: the trace kernels' mix (fma, integer add, compare + select, min/max, float->int)
+template <int KIND>
+__global__ __launch_bounds__(256) void k_valu_rate(float *sink, unsigned iters, long long *clocks)
+{
+    float    a[16];
+    unsigned u[16];
+    for (int i = 0; i < 16; ++i) { a[i] = (float)(threadIdx.x + i) * 0x1.0p-10f; u[i] = threadIdx.x * 16u + i; }
+    const float    x = 1.0f + (float)blockIdx.x * 0x1.0p-20f, y = 0x1.0p-12f;
+    const long long c0 = clock64(), w0 = wall_clock64();
+    for (unsigned it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < kRateUnroll / 16; ++r) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (KIND == 0) {
+                    asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(x), "v"(y));
+                } else if (KIND == 1) {
+                    asm volatile("v_add_u32 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 15]));
+                } else {
+                    switch ((i + 4 * r) & 7) {
+                        case 0: asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(x), "v"(y)); break;
+                        case 1: asm volatile("v_add_u32 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 15])); break;
+                        case 2: asm volatile("v_cmp_lt_f32 vcc, %1, %2\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(x), "v"(y) : "vcc"); break;
+                        case 3: asm volatile("v_min_i32 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 3) & 15])); break;
+                        case 4: asm volatile("v_cvt_i32_f32 %0, %1" : "=v"(u[i]) : "v"(a[i])); break;
+                        case 5: asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(x)); break;
+                        case 6: asm volatile("v_floor_f32 %0, %0" : "+v"(a[i])); break;
+                        default: asm volatile("v_xor_b32 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 5) & 15])); break;
+                    }
+                }
+            }
+        }
+    }
+    const long long c1 = clock64(), w1 = wall_clock64();
+    float s = 0.0f;
+    for (int i = 0; i < 16; ++i) s += a[i] + (float)u[i];
+    if (s == 123.456f) sink[0] = s;  // keeps the chains alive; practically never taken
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clocks[0] = c1 - c0; clocks[1] = w1 - w0; }
+}
+
+}  // namespace
+
+// Chip-wide rate of wave64 vector instructions with `waves_per_simd` (1..8) wavefronts resident on every
+// SIMD of every compute unit, each issuing a long stream of independent instructions of `kind` (0: v_fma_f32,
+// 1: v_add_u32, 2: a mix like the trace kernels').  out[0] = wave instructions per second, out[1] = shader
+// clock in GHz inside the kernel (shader ticks over 100 MHz wall ticks of the first wavefront's loop), out[2] = shader
+// cycles per wave instruction per SIMD at that clock (clock x SIMDs / rate), out[3] = kernel milliseconds (HIP events).  The mix counts its
+// compare + select pair as two instructions.  Returns 0, or the HIP error code.
+extern "C" int vrt_selftest_valu_rate(int device, int kind, int waves_per_simd, double out[4])
+{
+    if (kind < 0 || kind > 2 || waves_per_simd < 1 || waves_per_simd > 8 || !out) return (int)hipErrorInvalidValue;
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return (int)e;
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return (int)e;
+    const unsigned cus = (unsigned)prop.multiProcessorCount, blocks = cus * (unsigned)waves_per_simd;  // 256 threads = one wave per SIMD
+    const unsigned iters = 20000u / (unsigned)waves_per_simd + 1000u;
+    float *sink = nullptr;
+    long long *clocks = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    e = hipMalloc(&sink, 256);
+    if (e == hipSuccess) e = hipMalloc(&clocks, 2 * sizeof(long long));
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    float ms = 0.0f;
+    long long h[2] = {0, 0};
+    for (int rep = 0; rep < 2 && e == hipSuccess; ++rep) {  // the first launch warms the clocks up
+        e = hipEventRecord(e0, nullptr);
+        if (e != hipSuccess) break;
+        if (kind == 0) k_valu_rate<0><<<blocks, 256>>>(sink, iters, clocks);
+        else if (kind == 1) k_valu_rate<1><<<blocks, 256>>>(sink, iters, clocks);
+        else k_valu_rate<2><<<blocks, 256>>>(sink, iters, clocks);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    }
+    if (e == hipSuccess) e = hipMemcpy(h, clocks, sizeof h, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) {
+        // the mix's compare + select case is two instructions: 1 case in 8
+        const double per_iter = kind == 2 ? kRateUnroll * 9.0 / 8.0 : (double)kRateUnroll;
+        const double instr = (double)blocks * 4.0 * (double)iters * per_iter;
+        const double ghz = h[1] > 0 ? (double)h[0] / ((double)h[1] * 10.0) : 0.0;  // 100 MHz wall ticks
+        out[0] = instr / ((double)ms * 1e-3);
+        out[1] = ghz;
+        out[2] = out[0] > 0.0 ? ghz * 1e9 * (double)cus * 4.0 / out[0] : 0.0;  // cycles the chip's SIMDs spend per instruction
+        out[3] = (double)ms;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(sink);
+    (void)hipFree(clocks);
+    return (int)e;
+}
+
+// ---------------------------------------------------------------------------
+// Layout of the kernel-argument segment.  The trace kernels hand their seldom used code a pointer
+// to the segment instead of a copy of the launch parameters (degenerate_pixel, degenerate_primary,
+// degenerate_ray in vrt_trace.hip), on the assumption that a by-value TraceParams that is the kernel's
+// first parameter sits at offset 0 of the segment, with the struct's own layout.
+// ---------------------------------------------------------------------------
+namespace {
+
+__device__ unsigned count_kernarg_mismatches(const void *segment, const unsigned *expect, unsigned words)
+{
+    const unsigned *seg = static_cast<const unsigned *>(segment);
+    unsigned bad = 0;
+    for (unsigned i = threadIdx.x; i < words; i += blockDim.x) bad += seg[i] != expect[i] ? 1u : 0u;
+    return bad;
+}
+
+// the shape of k_trace_skip and k_trace_literal: the parameter block alone
+__global__ __launch_bounds__(64) void k_kernarg_alone(const vrt::TraceParams P, const unsigned *expect, unsigned *bad)
+{
+    const unsigned n = count_kernarg_mismatches((const void *)__builtin_amdgcn_kernarg_segment_ptr(), expect, sizeof(vrt::TraceParams) / 4);
+    if (n) atomicAdd(bad, n);
+    if (threadIdx.x == 0 && P.w != expect[16]) atomicAdd(bad, 1u << 16);  // m[16] comes first, then w
+}
+
+// the shape of k_trace_secondary: three pointers follow the block
+__global__ __launch_bounds__(64) void k_kernarg_with_tail(const vrt::TraceParams P, uint8_t *a, uint8_t *b, uint32_t *c,
+                                                          const unsigned *expect, unsigned *bad)
+{
+    const unsigned n = count_kernarg_mismatches((const void *)__builtin_amdgcn_kernarg_segment_ptr(), expect, sizeof(vrt::TraceParams) / 4);
+    if (n) atomicAdd(bad, n);
+    if (threadIdx.x == 0 && (P.w != expect[16] || a != nullptr || b != nullptr || c != nullptr)) atomicAdd(bad, 1u << 16);
+}
+
+}  // namespace
+
+// out[0], out[1] = 32-bit words of the kernel-argument segment that differ from the TraceParams the host
+// passed by value, for the two kernel shapes above (0 = the layout holds); out[2] = sizeof(TraceParams).
+// Returns 0, or the HIP error code.
+extern "C" int vrt_selftest_kernarg(int device, unsigned out[3])
+{
+    static_assert(sizeof(vrt::TraceParams) % 4 == 0, "TraceParams is compared word by word");
+    if (!out) return (int)hipErrorInvalidValue;
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return (int)e;
+    constexpr unsigned words = sizeof(vrt::TraceParams) / 4;
+    vrt::TraceParams p;
+    unsigned pattern[words];
+    for (unsigned i = 0; i < words; ++i) pattern[i] = 0x9e3779b9u * (i + 1u);  // every word distinct, padding included
+    static_assert(sizeof pattern == sizeof p, "pattern covers the block");
+    __builtin_memcpy(&p, pattern, sizeof p);
+    unsigned *d = nullptr;
+    e = hipMalloc(&d, sizeof pattern + 2 * sizeof(unsigned));
+    if (e != hipSuccess) return (int)e;
+    unsigned *bad = d + words;
+    e = hipMemcpy(d, pattern, sizeof pattern, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(bad, 0, 2 * sizeof(unsigned));
+    if (e == hipSuccess) {
+        k_kernarg_alone<<<1, 64>>>(p, d, bad);
+        k_kernarg_with_tail<<<1, 64>>>(p, nullptr, nullptr, nullptr, d, bad + 1);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(out, bad, 2 * sizeof(unsigned), hipMemcpyDeviceToHost);
+    out[2] = (unsigned)sizeof(vrt::TraceParams);
+    (void)hipFree(d);
     return (int)e;
 }

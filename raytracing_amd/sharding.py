@@ -27,7 +27,7 @@ def pose_indices(count, part, parts):
     return list(range(part, count, parts))
 
 
-def gather_frame(packed, h, strip_h, dst=0, group=None, out=None, core=None):
+def gather_frame(packed, h, strip_h, dst=0, group=None, out=None, core=None, pad_rows=None):
     """Gather every rank's packed rows (tensor [rows_r, ...]) to `dst` and return the full
     frame [h, ...] there (None elsewhere).  Ranks own different row counts when the strip
     count is not a multiple of the world size, so buffers are padded to the largest.
@@ -36,33 +36,46 @@ def gather_frame(packed, h, strip_h, dst=0, group=None, out=None, core=None):
     behind the trace on the context's stream and the rows are put back by one launch of the
     library's copy kernel (`vrt_assemble_strips`), enqueued on the same stream: call
     `core.sync()` before reading the frame.  Without it (host tensors, the gloo rehearsal)
-    the rows are put back with tensor indexing."""
+    the rows are put back with tensor indexing.  `pad_rows`: rows every rank's buffer is padded to (default
+    and minimum: the rows of the largest part; the same value on every rank)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    pad_rows = max_strip_rows(h, strip_h, world)
-    if packed.shape[0] != pad_rows:
+    most = max_strip_rows(h, strip_h, world)
+    pad_rows = most if pad_rows is None else int(pad_rows)
+    if pad_rows < most:
+        raise ValueError(f"pad_rows {pad_rows} is less than the {most} rows of the largest part")
+
+    def padded():
+        if packed.shape[0] == pad_rows:
+            return packed
         buf = packed.new_zeros((pad_rows,) + tuple(packed.shape[1:]))
         buf[:packed.shape[0]] = packed
-    else:
-        buf = packed
+        return buf
+
     if core is not None:
         if not packed.is_cuda:
             raise ValueError("gather_frame(core=...) takes device tensors")
+        # Everything that touches `packed` runs on the context's stream, behind the trace that fills it: the
+        # padding copy (ranks own different row counts when the strips do not divide evenly), the gather and
+        # the row reorder.  Buffers made here are used on that stream only and are recorded on it.
         stream = torch.cuda.ExternalStream(core.stream(), device=packed.device)
         with torch.cuda.stream(stream):
+            buf = padded()
+            buf.record_stream(stream)
             if rank != dst:
                 dist.gather(buf, None, dst=dst, group=group)
                 return None
             parts = torch.empty((world,) + tuple(buf.shape), dtype=buf.dtype, device=buf.device)
+            parts.record_stream(stream)
             dist.gather(buf, list(parts.unbind(0)), dst=dst, group=group)
             frame = out if out is not None else packed.new_empty((h,) + tuple(packed.shape[1:]))
             if not frame.is_contiguous() or frame.shape[0] != h:
                 raise ValueError("`out` must be a contiguous [h, ...] tensor")
             row_bytes = frame[0].numel() * frame.element_size()
             core.assemble_strips(parts.data_ptr(), frame.data_ptr(), row_bytes, h, strip_h, world, pad_rows)
-            parts.record_stream(stream)
             frame.record_stream(stream)
         return frame
+    buf = padded()
     if rank == dst:
         parts = [torch.empty_like(buf) for _ in range(world)]
         dist.gather(buf, parts, dst=dst, group=group)

@@ -79,11 +79,54 @@ def test_no_device_is_a_loud_error_not_a_fallback():
 
 
 def test_rust_declarations_name_every_symbol():
-    # rust/src/vrt_sys.rs cannot be compiled here; at least its extern block must list the header's functions
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    text = open(os.path.join(root, "rust", "src", "vrt_sys.rs")).read()
+    # rust/src/graphics/vrt_sys.rs cannot be compiled here; at least its extern block must list the header's functions
+    text = open(os.path.join(ROOT, "rust", "src", "graphics", "vrt_sys.rs")).read()
     rust = sorted(set(re.findall(r"pub fn (vrt_[a-z_0-9]+)\s*\(", text)))
     assert rust == declared_symbols()
+
+
+# What main.rs, game_logic and terrain of the reference use of `GraphicsCore`, as regular expressions over source
+# text with the whitespace squeezed: (pattern, file of the reference it is taken from).
+REFERENCE_SURFACE = [
+    (r"pub const CHUNK_SIZE: u32 = 32;", "src/graphics/mod.rs"),                                            # :147
+    (r"pub const CHUNK_SIZE_3: u32 = Self::CHUNK_SIZE \* Self::CHUNK_SIZE \* Self::CHUNK_SIZE;", "src/graphics/mod.rs"),  # :148
+    (r"pub\(crate\) fn reset_distance_field\(&mut self\)", "src/graphics/mod.rs"),                            # :150
+    (r"pub fn upload_chunk_gpu\(&mut self, chunk_pos: Vector3<i32>, _?game_state: &mut GameState\)", "src/graphics/mod.rs"),  # :245
+    (r"pub\(crate\) fn new\(\) -> \(EventLoop<\(\)>, GraphicsCore\)", "src/graphics/mod.rs"),                   # :292
+    (r"pub fn get_settings\(&self\) -> GraphicsSettings", "src/graphics/mod.rs"),                             # :426
+    (r"pub fn run\( ?mut self, event_loop: EventLoop<\(\)>, mut game_state: GameState, "
+     r"game_update: fn\(&mut GraphicsCore, &mut GameState\) -> PushConstants,? ?\) -> !", "src/graphics/mod.rs"),  # :430
+    (r"fn redraw\(&mut self, (mut )?push_constants: PushConstants\) -> bool", "src/graphics/mod.rs"),         # :531
+    (r"pub\(crate\) device: Arc<Device>,", "src/graphics/mod.rs"),                                            # :136
+    (r"pub\(crate\) previous_frame_end: Option<Box<dyn GpuFuture>>,", "src/graphics/mod.rs"),                 # :140
+    (r"pub struct PushConstants \{ pub transform: Matrix4<f32>, pub image_index: u32, \}", "src/graphics/push_constants.rs"),  # :6-9
+    (r"pub struct GraphicsSettings \{ pub\(crate\) render_distance: u8, (#\[allow\(dead_code\)\] )?fov: f64,( //[^\n]*?)? "
+     r"pub mouse_sensitivity: \(f32, f32\), \}", "src/graphics/graphics_settings.rs"),                         # :2-6
+    (r"pub fn default\(\) -> Self", "src/graphics/graphics_settings.rs"),                                     # :9
+]
+
+
+def squeeze(text):
+    text = re.sub(r"//[^\n]*", "", text)
+    return re.sub(r"\s+", " ", text)
+
+
+def test_rust_graphics_module_keeps_the_reference_signatures():
+    """rust/src/graphics/mod.rs (never compiled: no toolchain) declares every item the reference's callers use with
+    the reference's visibility, argument list and return type; where a checkout of the reference is present the
+    same patterns are checked against its own source, so that the list cannot drift from what it mirrors."""
+    ours = squeeze(open(os.path.join(ROOT, "rust", "src", "graphics", "mod.rs")).read())
+    for pattern, _ in REFERENCE_SURFACE:
+        assert re.search(pattern, ours), pattern
+    ref_root = "/root/reference"
+    if os.path.isdir(ref_root):
+        for pattern, rel in REFERENCE_SURFACE:
+            theirs = squeeze(open(os.path.join(ref_root, rel)).read())
+            assert re.search(pattern, theirs), (pattern, rel)
+    # the game loop's other lines that name vulkano compile against the stand-in crate
+    shim = open(os.path.join(ROOT, "rust", "shims", "vulkano", "src", "lib.rs")).read()
+    for name in ("pub trait GpuFuture", "fn then_signal_fence_and_flush", "fn boxed", "pub fn now", "pub fn wait", "pub trait Pipeline"):
+        assert name in shim, name
 
 
 def test_selftest_library_loads():
@@ -91,4 +134,5 @@ def test_selftest_library_loads():
     import os
     from raytracing_amd import _lib as L
     lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(L.__file__)), "libvrt_selftest.so"))
-    assert hasattr(lib, "vrt_selftest_recip")
+    for name in ("vrt_selftest_recip", "vrt_selftest_valu_rate", "vrt_selftest_kernarg"):
+        assert hasattr(lib, name), name

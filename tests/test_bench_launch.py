@@ -1,0 +1,48 @@
+"""`python bench.py --gpus N` started plainly (no launcher, no WORLD_SIZE): the parent starts one rank per GPU
+through torch.distributed.run as a child process, relays rank 0's JSON line and exits with the child's code."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*flags, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, env=env, timeout=timeout)
+    return p
+
+
+def json_lines(text):
+    return [json.loads(l) for l in text.splitlines() if l.lstrip().startswith("{")]
+
+
+def test_plain_start_with_two_ranks_launches_them_itself():
+    p = run_bench("--gpus", "2", "--steps", "2", "--launch-check")
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = json_lines(p.stdout)
+    assert len(lines) == 1, p.stdout
+    assert lines[0]["n_gpus"] == 2 and lines[0]["ranks_seen"] == 2 and lines[0]["steps"] == 2
+
+
+def test_rank_count_that_disagrees_with_gpus_is_refused():
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE=3" in p.stderr and not p.stdout.strip()
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_over_gloo_print_one_line():
+    """The whole multi-rank bench (replicated worlds, one pose per rank, framebuffer gather to rank 0), started
+    plainly, with both ranks sharing the one GPU of the box and the gather going through host memory."""
+    p = run_bench("--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--probe", "16")
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = json_lines(p.stdout)
+    assert len(lines) == 1, p.stdout
+    assert lines[0]["n_gpus"] == 2 and lines[0]["steps"] == 2 and lines[0]["value"] > 0
+    assert lines[0]["scaling"] == "weak" and lines[0]["roofline"]["timed_launches"] >= 16

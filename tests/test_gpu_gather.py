@@ -1,0 +1,57 @@
+"""The device path of sharding.gather_frame on the GPU box: one rank, RCCL, the context's own stream.  The
+padding copy, the gather and the row reorder must all be ordered behind the trace that fills the packed
+buffer (a stream the default stream does not wait for), so the frame is compared on every one of many
+back-to-back rounds, each with a different camera."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+
+from raytracing_amd import GraphicsCore, Player, TRACE_SKIP, VOXEL_PACKED_U8, scenes, sharding
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.fixture(scope="module")
+def single_rank_rccl():
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    yield
+    dist.destroy_process_group()
+
+
+def test_padded_strip_buffers_are_gathered_behind_the_trace(single_rank_rccl):
+    W, H, strip_h, n = 1920, 1080, 8, 256          # 135 strips of 8 rows
+    p0 = scenes.pose_b()
+    with GraphicsCore(grid_n=n, voxel_format=VOXEL_PACKED_U8, trace_mode=TRACE_SKIP) as g:
+        g.generate_window(scenes.window_min(p0.get_position(), n))
+        g.reset_distance_field()
+        rows = sharding.max_strip_rows(H, strip_h, 1)
+        assert rows == H
+        packed = torch.zeros((rows, W, 4), dtype=torch.uint8, device="cuda")
+        whole = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        for i in range(24):
+            cam = scenes.cam16(Player.at(p0.get_position(), scenes.POSE_B_YAW + 0.21 * i, scenes.POSE_B_PITCH))
+            g.trace_strips_device(cam, W, H, strip_h, 0, 1, {"bgra8": packed.data_ptr()})
+            # padded by 40 rows: the copy into the padded buffer is the step that must wait for the trace
+            frame = sharding.gather_frame(packed, H, strip_h, dst=0, core=g, pad_rows=rows + 40)
+            g.trace_device(cam, W, H, 0, H, {"bgra8": whole.data_ptr()})
+            g.sync()
+            torch.cuda.synchronize()
+            assert torch.equal(frame, whole), i
+        with pytest.raises(ValueError):
+            sharding.gather_frame(packed, H, strip_h, dst=0, core=g, pad_rows=rows - 1)

@@ -88,6 +88,40 @@ def test_fast_reciprocal_is_the_division_for_every_float():
     assert (out[0], out[1]) == (0, 0), f"values differ for {out[0]} arguments, classes for {out[1]}; first 0x{out[2]:08x}"
 
 
+def _selftest_lib():
+    import os
+    return C.CDLL(os.path.join(os.path.dirname(os.path.abspath(L.__file__)), "libvrt_selftest.so"))
+
+
+def test_kernel_argument_segment_starts_with_the_parameter_block():
+    """The trace kernels pass their out-of-line code a pointer to the kernel-argument segment in place of a
+    copy of TraceParams (vrt_trace.hip: degenerate_pixel, degenerate_primary, degenerate_ray).  That holds
+    only while a by-value first parameter sits at offset 0 of the segment with the struct's own layout:
+    checked word by word on the device, for both kernel shapes (parameter block alone, and followed by
+    three pointers)."""
+    lib = _selftest_lib()
+    lib.vrt_selftest_kernarg.restype = C.c_int
+    lib.vrt_selftest_kernarg.argtypes = [C.c_int, C.POINTER(C.c_uint)]
+    out = (C.c_uint * 3)()
+    assert lib.vrt_selftest_kernarg(0, out) == 0
+    assert (out[0], out[1]) == (0, 0), f"{out[0]} / {out[1]} words of {out[2] // 4} differ"
+    assert out[2] % 8 == 0
+
+
+def test_vector_issue_rate_microbenchmark_is_sane():
+    """The rate that prices the skip kernel's roof (bench.py): wave64 vector instructions per second with
+    eight wavefronts on every SIMD.  Bounds only: between 1 and 4.5 shader cycles per instruction per SIMD."""
+    lib = _selftest_lib()
+    lib.vrt_selftest_valu_rate.restype = C.c_int
+    lib.vrt_selftest_valu_rate.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    for kind in (0, 1, 2):
+        out = (C.c_double * 4)()
+        assert lib.vrt_selftest_valu_rate(0, kind, 8, out) == 0
+        rate, ghz, cyc, ms = out[0], out[1], out[2], out[3]
+        print(f"valu kind {kind}: {rate / 1e9:.1f} G wave-instr/s, {ghz:.2f} GHz, {cyc:.2f} cycles/instr/SIMD, {ms:.2f} ms")
+        assert 1.0 < ghz < 3.0 and 0.9 < cyc < 4.6 and 3e11 < rate < 3e12
+
+
 @pytest.mark.parametrize("mode", MODES)
 def test_transforms_that_are_not_rotations(scene160, mode):
     """The ABI takes any finite 4x4: scaled, sheared and mirrored bases, a bottom row that is not (0,0,0,1)

@@ -110,6 +110,22 @@ int vrt_reset_distance_field(vrt_ctx *ctx);
 int vrt_trace(vrt_ctx *ctx, const float cam_col_major[16], uint32_t w, uint32_t h,
               uint32_t y0, uint32_t y1, const vrt_outputs *out);
 
+/* vrt_trace for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  It has NO counterpart in the reference.  Same arguments, same planes, same kernels as
+ * vrt_trace, with two differences.  (1) It makes no hipMalloc / hipFree / hipHostMalloc call and none that
+ * allocates behind the scenes: the per-frame tables and the dispatch-order slots that a trace launch needs beyond
+ * the world and the caller's planes live in a static device array of the library (1 165 576 bytes per GPU, held
+ * until the process ends) instead of the context's own buffers.  (2) Therefore: DEVICE planes only; frames of at
+ * most 8192 x 8192 pixels and 131 072 wavefronts of 64 pixels (3840 x 2160 has 129 600); grid_n at most 4096;
+ * and the traversal index must be current -- call vrt_reset_distance_field (or vrt_trace once) after the last
+ * change to the world, else VRT_E_UNSUPPORTED.  Anything beyond these limits is VRT_E_INVALID_ARG with a message.
+ * Every context on one GPU shares that GPU's array, which keeps the last call's tables and measurements (the
+ * library refills and re-tags what a call needs): calls that overlap on one GPU -- two streams, two threads --
+ * race on it; calls on one stream, or separated by vrt_sync, do not.  No HIP events are recorded (vrt_kernel_time
+ * does not see these launches).  The call only enqueues work on the context's stream. */
+int vrt_trace_static(vrt_ctx *ctx, const float cam_col_major[16], uint32_t w, uint32_t h,
+                     uint32_t y0, uint32_t y1, const vrt_outputs *out);
+
 /* Secondary rays per primary hit: one shadow ray towards normalize(0.4, 0.8, 0.45) and four
  * cosine-distributed ambient-occlusion rays about the face normal (hash chain
  * pcg(0x5EED ^ (row*w + col))), origin hit_point + normal*1e-3, traced by the skip kernel in

@@ -55,6 +55,7 @@ SYMBOLS = {
     "vrt_generate_window": (C.c_int, [_CTX, C.POINTER(C.c_int32)]),
     "vrt_reset_distance_field": (C.c_int, [_CTX]),
     "vrt_trace": (C.c_int, [_CTX, _F, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(VrtOutputs)]),
+    "vrt_trace_static": (C.c_int, [_CTX, _F, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(VrtOutputs)]),
     "vrt_trace_secondary": (C.c_int, [_CTX, _F, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                       C.POINTER(VrtSecondaryOutputs)]),
     "vrt_trace_strips": (C.c_int, [_CTX, _F, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,

@@ -45,7 +45,8 @@ constexpr size_t   kSchedHead = 2 + 2 * kSchedRows;
 // about its contents:
 //   tables  ncx[max_dim] | ncy[max_dim + 1] | sin2[3][grid_n + 8]        (TraceParams::ncx, ncy, sin2)
 //   sched   start[2] | row_longest[2][256] | cost[2][sched_capacity]      (vrt::RowSched)
-// A context owns one (allocated in vrt_create).
+// A context owns one (allocated in vrt_create); vrt_trace_static uses the one that lives in the library's
+// static device array, one per device.
 struct Scratch {
     float    *tables        = nullptr;
     uint32_t  max_dim       = 0;         // frame width / height the tables have room for
@@ -62,6 +63,51 @@ struct Scratch {
     size_t table_floats() const { return (size_t)2 * max_dim + 1 + 3 * (size_t)sin_cap; }
     size_t sched_bytes() const { return (kSchedHead + 2 * (size_t)sched_capacity) * sizeof(uint32_t); }
 };
+
+// ---- the static scratch of vrt_trace_static ---------------------------------------------------------
+// Limits of that entry point: frames of at most 8192 x 8192 pixels and 131072 wavefronts of 64 pixels
+// (3840 x 2160 has 129600), grids of at most 4096 voxels per axis.
+constexpr uint32_t kStaticMaxDim      = 8192;
+constexpr uint32_t kStaticMaxGrid     = 4096;
+constexpr uint32_t kStaticSchedCap    = 131072;
+constexpr size_t   kStaticTableBytes  = ((size_t)2 * kStaticMaxDim + 1 + 3 * (size_t)(kStaticMaxGrid + 8)) * sizeof(float);
+constexpr size_t   kStaticSchedOffset = (kStaticTableBytes + 255) & ~(size_t)255;
+constexpr size_t   kStaticSchedBytes  = (kSchedHead + 2 * (size_t)kStaticSchedCap) * sizeof(uint32_t);
+constexpr size_t   kStaticScratchBytes = kStaticSchedOffset + kStaticSchedBytes;  // 1 165 576 bytes
+
+// One copy per GPU the library runs on, held until the process ends.  In host code this name is only a
+// stand-in for the symbol: the device address comes from hipGetSymbolAddress (static_scratch_for) and is
+// what every kernel argument, memset and copy below uses.
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+constexpr int kMaxDevices = 64;
+struct StaticScratch {
+    bool    ready = false;
+    Scratch s;
+};
+StaticScratch g_static[kMaxDevices];  // one GPU's static calls may not overlap; neither may contexts be created concurrently
+
+// The device's own copy of `scratch`, looked up once per device with that device current.
+int static_scratch_for(int device, Scratch **out)
+{
+    if (device < 0 || device >= kMaxDevices) return fail(VRT_E_INVALID_ARG, "device %d beyond the %d the static scratch covers", device, kMaxDevices);
+    StaticScratch &st = g_static[device];
+    if (!st.ready) {
+        HIP_TRY(hipSetDevice(device));
+        void *ptr = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr) return fail(VRT_E_HIP, "hipGetSymbolAddress returned no address for the static scratch");
+        st.s = Scratch{};
+        st.s.tables = static_cast<float *>(ptr);
+        st.s.max_dim = kStaticMaxDim;
+        st.s.sin_cap = kStaticMaxGrid + 8;
+        st.s.sched = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(ptr) + kStaticSchedOffset);
+        st.s.sched_capacity = kStaticSchedCap;
+        st.ready = true;  // the array is zero when the code object is loaded: generation tags start clean
+    }
+    *out = &st.s;
+    return VRT_OK;
+}
 
 }  // namespace
 
@@ -389,6 +435,12 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out)
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(VRT_E_NO_DEVICE, "no HIP device available");
     if (cfg->device < 0 || cfg->device >= count) return fail(VRT_E_NO_DEVICE, "device %d out of range (%d devices)", cfg->device, count);
     HIP_TRY(hipSetDevice(cfg->device));
+    {   // the static scratch of vrt_trace_static: its address on this device, taken now so that the entry point itself
+        // has no set-up left to do
+        Scratch *unused = nullptr;
+        int rc = static_scratch_for(cfg->device, &unused);
+        if (rc != VRT_OK) return rc;
+    }
 
     vrt_ctx *c = new (std::nothrow) vrt_ctx();
     if (!c) return fail(VRT_E_OUT_OF_MEMORY, "host allocation failed");
@@ -517,6 +569,37 @@ int vrt_trace(vrt_ctx *c, const float cam[16], uint32_t w, uint32_t h, uint32_t 
     if (y0 > y1 || y1 > h) return fail(VRT_E_INVALID_ARG, "row band [%u,%u) outside the frame", y0, y1);
     vrt::RowMap rows{y0, y1 - y0, 0, 0, 1};
     return do_trace(c, cam, w, h, rows, out);
+}
+
+int vrt_trace_static(vrt_ctx *c, const float cam[16], uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, const vrt_outputs *out)
+{
+    if (!c || !cam || !out) return fail(VRT_E_INVALID_ARG, "null argument");
+    if (out->struct_size != sizeof(vrt_outputs)) return fail(VRT_E_INVALID_ARG, "vrt_outputs.struct_size mismatch");
+    if (out->memory != VRT_MEM_DEVICE)
+        return fail(VRT_E_INVALID_ARG, "vrt_trace_static writes DEVICE planes only (host planes need a staging buffer)");
+    if (y0 > y1 || y1 > h) return fail(VRT_E_INVALID_ARG, "row band [%u,%u) outside the frame", y0, y1);
+    if (w == 0 || h == 0 || w > kStaticMaxDim || h > kStaticMaxDim)
+        return fail(VRT_E_INVALID_ARG, "frame %u x %u beyond the static scratch's %u x %u", w, h, kStaticMaxDim, kStaticMaxDim);
+    if (c->n > kStaticMaxGrid) return fail(VRT_E_INVALID_ARG, "grid_n %u beyond the static scratch's %u", c->n, kStaticMaxGrid);
+    {   // the dispatch-order slots: one per wavefront of the launch
+        const uint32_t lh = c->knob_tile_log2h, tw = 64u >> lh, bh = 4u << lh;
+        const uint64_t waves = (uint64_t)((w + tw - 1) / tw) * ((y1 - y0 + bh - 1) / bh) * 4u;
+        if (waves > kStaticSchedCap)
+            return fail(VRT_E_INVALID_ARG, "%llu wavefronts of 64 pixels beyond the static scratch's %u (3840 x 2160 has 129600)",
+                        (unsigned long long)waves, kStaticSchedCap);
+    }
+    Scratch *S = nullptr;
+    { int rc = static_scratch_for(c->device, &S); if (rc != VRT_OK) return rc; }
+    vrt::RowMap rows{y0, y1 - y0, 0, 0, 1};
+    vrt::TraceParams p;
+    bool use_skip = false;
+    { int rc = prepare_trace(c, *S, false, cam, w, h, rows, false, p, use_skip); if (rc != VRT_OK) return rc; }
+    p.bgra8 = out->bgra8; p.voxel = out->voxel; p.face = out->face; p.steps = out->steps;
+    p.t = out->t; p.hit_point = out->hit_point; p.rgba = out->rgba;
+    if (use_skip) { int rc = attach_row_sched(c, *S, p, 1); if (rc != VRT_OK) return rc; }
+    if (use_skip) { HIP_TRY(vrt::launch_trace_skip(p, c->voxel_bytes, c->stream)); c->last_kernel = "skip"; }
+    else          { HIP_TRY(vrt::launch_trace_literal(p, c->voxel_bytes, c->stream)); c->last_kernel = "literal"; }
+    return VRT_OK;
 }
 
 int vrt_trace_secondary(vrt_ctx *c, const float cam[16], uint32_t w, uint32_t h, uint32_t y0, uint32_t y1,

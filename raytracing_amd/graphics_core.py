@@ -206,6 +206,13 @@ class GraphicsCore:
         o = L.VrtOutputs(C.sizeof(L.VrtOutputs), L.MEM_DEVICE, *[ptrs.get(k) for k in _PLANES])
         L.check(L.lib().vrt_trace(self._ctx, camp, w, h, y0, y1, C.byref(o)))
 
+    def trace_static_device(self, cam, w, h, y0, y1, ptrs):
+        """`trace_device` through the entry point that allocates nothing (`vrt_trace_static`): the launch's
+        tables and dispatch-order slots live in the library's static device array."""
+        cam, camp = self._cam(cam)
+        o = L.VrtOutputs(C.sizeof(L.VrtOutputs), L.MEM_DEVICE, *[ptrs.get(k) for k in _PLANES])
+        L.check(L.lib().vrt_trace_static(self._ctx, camp, w, h, y0, y1, C.byref(o)))
+
     def trace_strips_device(self, cam, w, h, strip_h, part, parts, ptrs):
         cam, camp = self._cam(cam)
         o = L.VrtOutputs(C.sizeof(L.VrtOutputs), L.MEM_DEVICE, *[ptrs.get(k) for k in _PLANES])

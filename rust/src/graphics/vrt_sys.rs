@@ -54,6 +54,7 @@ extern "C" {
     pub fn vrt_generate_window(ctx: *mut VrtCtx, wmin: *const i32) -> c_int;
     pub fn vrt_reset_distance_field(ctx: *mut VrtCtx) -> c_int;
     pub fn vrt_trace(ctx: *mut VrtCtx, cam_col_major: *const f32, w: u32, h: u32, y0: u32, y1: u32, out: *const VrtOutputs) -> c_int;
+    pub fn vrt_trace_static(ctx: *mut VrtCtx, cam_col_major: *const f32, w: u32, h: u32, y0: u32, y1: u32, out: *const VrtOutputs) -> c_int;
     pub fn vrt_trace_secondary(ctx: *mut VrtCtx, cam_col_major: *const f32, w: u32, h: u32, y0: u32, y1: u32, out: *const VrtSecondaryOutputs) -> c_int;
     pub fn vrt_trace_strips(ctx: *mut VrtCtx, cam_col_major: *const f32, w: u32, h: u32, strip_h: u32, part: u32, parts: u32, out: *const VrtOutputs) -> c_int;
     pub fn vrt_strip_rows(h: u32, strip_h: u32, part: u32, parts: u32) -> u32;

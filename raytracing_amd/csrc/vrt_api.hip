@@ -139,8 +139,10 @@ struct vrt_ctx {
     //   VRT_NO_ROW_ORDER=1  workgroup rows always top to bottom
     //   VRT_ROW_BLOCK0=r    workgroup rows always start at row block r
     //   VRT_SCHED_DEBUG=1   print what each launch measured for the dispatch order (synchronises)
+    //   VRT_SECONDARY=pixel vrt_trace_secondary runs every pixel's rays on the pixel's own lane instead of staging
+    //                       and binning the workgroup's rays in LDS (same outputs; for A/B measurements)
     uint32_t    knob_tile_log2h = 2;
-    bool        knob_no_row_order = false, knob_sched_debug = false;
+    bool        knob_no_row_order = false, knob_sched_debug = false, knob_secondary_binned = true;
     int32_t     knob_row_block0 = -1;
     // staging for host-resident outputs
     void       *d_stage      = nullptr;
@@ -455,6 +457,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out)
     if (const char *v = std::getenv("VRT_NO_ROW_ORDER")) c->knob_no_row_order = v[0] == '1';
     if (const char *v = std::getenv("VRT_ROW_BLOCK0")) c->knob_row_block0 = std::atoi(v);
     if (const char *v = std::getenv("VRT_SCHED_DEBUG")) c->knob_sched_debug = v[0] == '1';
+    if (const char *v = std::getenv("VRT_SECONDARY")) c->knob_secondary_binned = std::strcmp(v, "pixel") != 0;
     auto bail = [&](int code) { vrt_destroy(c); return code; };
 #define TRY_OR_BAIL(expr)                                                                                     \
     do {                                                                                                      \
@@ -630,7 +633,8 @@ int vrt_trace_secondary(vrt_ctx *c, const float cam[16], uint32_t w, uint32_t h,
     const int e = c->ev_pending;
     if (timed) HIP_TRY(hipEventRecord(c->ev0[e], c->stream));
     { int rc = attach_row_sched(c, c->own, p, 2); if (rc != VRT_OK) return rc; }
-    HIP_TRY(vrt::launch_trace_secondary(p, c->voxel_bytes, (uint8_t *)dev[0], (uint8_t *)dev[1], (uint32_t *)dev[2], c->stream));
+    HIP_TRY(vrt::launch_trace_secondary(p, c->voxel_bytes, c->knob_secondary_binned, (uint8_t *)dev[0], (uint8_t *)dev[1],
+                                        (uint32_t *)dev[2], c->stream));
     c->last_kernel = "secondary";
     if (timed) { HIP_TRY(hipEventRecord(c->ev1[e], c->stream)); c->ev_pending = e + 1; }
     if (out->memory == VRT_MEM_HOST) {

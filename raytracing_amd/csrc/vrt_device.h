@@ -30,6 +30,14 @@ VRT_DEV int f2i(float x)
 // float -> int for values known to be finite and far inside the int range.
 VRT_DEV int f2i_small(float x) { return (int)x; }
 
+// The same value, as far as the optimiser can tell a new one: what is computed from it is computed again
+// instead of being kept in registers from an earlier computation.
+VRT_DEV unsigned opaque(unsigned v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 // wrapping integer arithmetic
 VRT_DEV int wadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
 VRT_DEV int wsub(int a, int b) { return (int)((unsigned)a - (unsigned)b); }

@@ -88,7 +88,9 @@ struct TraceParams {
 // traversal kernels
 hipError_t launch_trace_literal(const TraceParams &p, int voxel_bytes, hipStream_t s);
 hipError_t launch_trace_skip(const TraceParams &p, int voxel_bytes, hipStream_t s);
-hipError_t launch_trace_secondary(const TraceParams &p, int voxel_bytes, uint8_t *shadow, uint8_t *ao,
+// binned: the workgroup's secondary rays staged in LDS and sorted by direction class (k_trace_secondary_binned);
+// else every pixel's rays on the pixel's own lane (k_trace_secondary).  Same outputs.
+hipError_t launch_trace_secondary(const TraceParams &p, int voxel_bytes, bool binned, uint8_t *shadow, uint8_t *ao,
                                   uint32_t *sec_steps, hipStream_t s);
 
 // world kernels

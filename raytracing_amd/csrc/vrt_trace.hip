@@ -469,7 +469,10 @@ struct CellRay {
     }
 
     // a ray that ended elsewhere: the loop has nothing to do for this lane
-    VRT_DEV void idle() { live = false; hit = false; work = 0; iters = 0; }
+    VRT_DEV void idle() { live = false; hit = false; work = 0; iters = 0; wx = wy = wz = w0 = 0; }
+
+    // iterations of the reference's loop so far (every step moves one axis by +1 in the mirrored frame)
+    VRT_DEV unsigned steps_done() const { return (unsigned)(wx + wy + wz - w0); }
 
     // One trip for the lanes with a live ray.  On entry the current voxel has been tested (or is the
     // start voxel) and lies inside the loaded area.
@@ -642,11 +645,24 @@ VRT_DEV void traverse_auto(const TraceParams &P, float rox, float roy, float roz
 // ---------------------------------------------------------------------------
 // per-pixel prologue / epilogue shared by both kernels
 // ---------------------------------------------------------------------------
+// The launch parameters as they lie in the kernel-argument segment (TraceParams is the first parameter of
+// every trace kernel, at offset 0: vrt_selftest_kernarg checks that), through a pointer the optimiser
+// cannot trace back: loads through it are scalar loads issued where the code stands, not hoisted to the
+// start of the kernel and held in scalar registers across the traversal loop.  Only valid in a kernel.
+typedef const __attribute__((address_space(4))) TraceParams KernargParams;
+VRT_DEV KernargParams *kernarg_again()
+{
+    KernargParams *p = (KernargParams *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
 // Wave tile = (64 >> tile_log2h) x (1 << tile_log2h) pixels; a workgroup stacks its four waves
 // vertically.  tile_log2h = 3 gives 8x8-pixel waves in a 8x32 block.  `by` is the workgroup row.
-VRT_DEV bool pixel_of_thread(const TraceParams &P, unsigned by, unsigned &col, unsigned &q, unsigned &row)
+template <typename PARAMS>
+VRT_DEV bool pixel_of_thread(const PARAMS &P, unsigned by, unsigned tid, unsigned &col, unsigned &q, unsigned &row)
 {
-    const unsigned tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const unsigned wave = tid >> 6, lane = tid & 63;
     const unsigned lh = P.tile_log2h, tw = 64u >> lh;
     col = blockIdx.x * tw + (lane & (tw - 1));
     q   = ((by * 4 + wave) << lh) + (lane >> (6 - lh));
@@ -784,7 +800,8 @@ VRT_DEV void raygen(const TraceParams &P, unsigned gx, unsigned gy, float &rdx, 
 
 // sin(floor(hit + 0.001) * 2) of raytrace.glsl:131 for axis k: from the frame's table when the floored
 // coordinate is in it (always, for a hit inside the loaded area), else evaluated
-VRT_DEV float shade_sine(const TraceParams &P, int k, float h)
+template <typename PARAMS>
+VRT_DEV float shade_sine(const PARAMS &P, int k, float h)
 {
     const float f = floorf(h + 0.001f);
     if (P.sin2) {
@@ -820,7 +837,8 @@ hipError_t launch_frame_tables(float *ncx, float *ncy, float *sin2, uint32_t w, 
 }
 
 // raytrace.glsl:129-133 + render.comp:9-13
-VRT_DEV void finish_pixel(const TraceParams &P, unsigned gx, unsigned gy, size_t i, const RayHit &H)
+template <typename PARAMS>
+VRT_DEV void finish_pixel(const PARAMS &P, unsigned gx, unsigned gy, size_t i, const RayHit &H)
 {
     float r, g, b, a = 1.0f;
     if (H.hit) {
@@ -858,7 +876,7 @@ template <typename T, bool HAS_DIST>
 __global__ __launch_bounds__(256) void k_trace_literal(const TraceParams P)
 {
     unsigned col, q, row;
-    if (!pixel_of_thread(P, blockIdx.y, col, q, row)) return;
+    if (!pixel_of_thread(P, blockIdx.y, threadIdx.x, col, q, row)) return;
     const unsigned gx = col, gy = P.h - row;  // render.comp:13
     float rdx, rdy, rdz;
     raygen(P, gx, gy, rdx, rdy, rdz);
@@ -895,24 +913,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 {
     const unsigned by = sched_row(P);
     unsigned col, q, row, work = 0;
-    if (pixel_of_thread(P, by, col, q, row)) {
+    if (pixel_of_thread(P, by, threadIdx.x, col, q, row)) {
 #ifdef VRT_DIAG_CLOCK
         const long long d0 = wall_clock64();
 #endif
-        const unsigned gx = col, gy = P.h - row;
         float rdx, rdy, rdz;
-        raygen(P, gx, gy, rdx, rdy, rdz);
+        raygen(P, col, P.h - row, rdx, rdy, rdz);
         const float rox = P.m[12], roy = P.m[13], roz = P.m[14];
         // loaded area (raytrace.glsl:19-24), evaluated once per frame on the host
         const int lox = P.lo[0], loy = P.lo[1], loz = P.lo[2], upx = P.up[0], upy = P.up[1], upz = P.up[2];
         const bool regular = FORM == FORM_CAPPED || ray_is_regular(rdx, rdy, rdz);
+        RayHit H;
         if (regular) {
-            RayHit H;
             if (FORM == FORM_CAPPED) traverse_skip<T>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
             else traverse_cells_regular<T, FORM == FORM_POW2>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, H);
             work = H.work;
-            finish_pixel(P, gx, gy, (size_t)q * P.w + col, H);
         }
+        // What follows the traversal loop takes nothing over from before it but the ray's result: the pixel's
+        // coordinates are worked out again from the thread index, and the launch parameters are read again
+        // from the kernel-argument segment.  The loop has no register to spare at 64 per lane (kept across it,
+        // one of the coordinates went to scratch memory: 4 bytes per lane written and read back per launch).
+        const KernargParams &K = *kernarg_again();
+        pixel_of_thread(K, by, opaque(threadIdx.x), col, q, row);
+        const unsigned gx = col, gy = K.h - row;
+        if (regular) finish_pixel(K, gx, gy, (size_t)q * K.w + col, H);
         if (!regular)  // (the builtin is only valid in the kernel itself; TraceParams sits at offset 0 of the segment)
             work = degenerate_pixel<T, FORM>((const TraceParams *)__builtin_amdgcn_kernarg_segment_ptr(), gx, gy, q);
 #ifdef VRT_DIAG_CLOCK
@@ -1005,7 +1029,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 {
     const unsigned by = sched_row(P);
     unsigned col, q, row, work = 0;
-    if (pixel_of_thread(P, by, col, q, row)) {
+    if (pixel_of_thread(P, by, threadIdx.x, col, q, row)) {
         const unsigned gx = col, gy = P.h - row;
         float rdx, rdy, rdz;
         raygen(P, gx, gy, rdx, rdy, rdz);
@@ -1060,9 +1084,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                     const unsigned r = degenerate_ray<T, FORM>(params, sox, soy, soz, sdx, sdy, sdz);
                     S.hit = (int)(r >> 31); S.steps = r & 0x7fffffffu; S.work = 0;
                 }
+#ifdef VRT_DIAG_SEC_TRIPS
+                // diagnostic build: trips of the two-phase loop instead of results (shadow: the shadow ray's,
+                // ao: the longest ambient-occlusion ray's, both capped at 255; sec_steps: the sum over the five)
+                st += S.work;
+                if (s == 0) sh = min(S.work, 255u); else occ = max(occ, min(S.work, 255u));
+#else
                 st += S.steps;
-                work += S.work;
                 if (S.hit) { if (s == 0) sh = 1; else ++occ; }
+#endif
+                work += S.work;
             }
         }
         const size_t i = (size_t)q * P.w + col;
@@ -1073,6 +1104,182 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     if (P.sched.cost) {
         sched_end(P, by, work);
         // the bookkeeping is done by the workgroups that start first, which are far from the end of the launch
+        const unsigned first = blockIdx.y * gridDim.x + blockIdx.x;
+        if (first < gridDim.y && threadIdx.x < 64) {
+            sched_reduce_row(P, first);
+            if (first == 0) sched_plan(P);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// secondary rays, staged in LDS and binned by direction class
+// ---------------------------------------------------------------------------
+// k_trace_secondary gives every pixel's five rays to the pixel's own lane, pass by pass: lanes whose primary
+// ray missed idle through all five passes, and the four ambient-occlusion rays a wavefront traces together
+// point anywhere in their hemispheres.  Here the workgroup (a 16 x 16 pixel tile) turns its primary hits into
+// a list of rays in LDS -- one 16-bit record per ray (pixel of the tile, ray index); origin and face once per
+// pixel; the direction is re-derived from the pixel's hash by whoever traces the ray -- sorted by direction
+// class (counting sort over LDS counters): ambient-occlusion rays by elevation above their surface in sixteen
+// classes, the shallowest (which skim the terrain and run longest) first, the shadow rays (one direction for
+// the whole frame) last.  The four wavefronts then pull 64 consecutive rays at a time from the list through an
+// LDS ticket until it is empty; no lane idles for a pixel that missed, a wavefront's rays have alike
+// elevations, and a wavefront that draws short rays takes more of them.  Results are summed per pixel with
+// LDS atomics (integer sums: the order of arrival does not matter) and stored by the pixel's own lane.
+constexpr unsigned SEC_BINS = 17;  // 16 elevation classes of ambient-occlusion rays + the shadow rays
+#ifndef VRT_SEC_REFILL
+#define VRT_SEC_REFILL 24
+#endif
+constexpr unsigned SEC_REFILL = VRT_SEC_REFILL;  // free lanes at which a wavefront draws new rays (1..64; 64: whole bundles)
+
+template <typename T, int FORM>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_trace_secondary_binned(const TraceParams P, uint8_t *shadow, uint8_t *ao, uint32_t *sec_steps)
+{
+    __shared__ float          s_org[3][256];   // origin of the pixel's secondary rays
+    __shared__ unsigned char  s_face[256];     // face of the primary hit, 0xff: no hit
+    __shared__ unsigned       s_steps[256];    // loop iterations summed over the pixel's rays
+    __shared__ unsigned       s_hits[256];     // bit 0: the shadow ray hit; bits 8..: ambient-occlusion rays that hit
+    __shared__ unsigned short s_ray[5 * 256];  // the sorted list: pixel | ray index << 8
+    __shared__ unsigned       s_count[SEC_BINS], s_base[SEC_BINS], s_next, s_total;
+
+    const unsigned tid = threadIdx.x;
+    const unsigned by = sched_row(P);
+    if (tid < SEC_BINS) s_count[tid] = 0;
+    if (tid == 0) s_next = 0;
+    s_steps[tid] = 0; s_hits[tid] = 0; s_face[tid] = 0xff;
+    __syncthreads();
+
+    // ---- phase 1: the primary ray of this lane's pixel
+    unsigned col, q, row, work = 0;
+    unsigned bins = 0;  // five 5-bit bin numbers of this pixel's rays, ray 0 lowest; only meaningful after a hit
+    bool     hit = false;
+    const bool inside = pixel_of_thread(P, by, tid, col, q, row);
+    if (inside) {
+        const unsigned gx = col, gy = P.h - row;
+        float rdx, rdy, rdz;
+        raygen(P, gx, gy, rdx, rdy, rdz);
+        const float rox = P.m[12], roy = P.m[13], roz = P.m[14];
+        const int lox = P.lo[0], loy = P.lo[1], loz = P.lo[2], upx = P.up[0], upy = P.up[1], upz = P.up[2];
+        const TraceParams *params = (const TraceParams *)__builtin_amdgcn_kernarg_segment_ptr();  // P sits at offset 0
+        RayHit H;
+        if (FORM == FORM_CAPPED) {
+            traverse_skip<T>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
+        } else if (ray_is_regular(rdx, rdy, rdz)) {
+            traverse_cells_regular<T, FORM == FORM_POW2>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, H);
+        } else {
+            float hp[3];
+            const unsigned r = degenerate_primary<T, FORM>(params, gx, gy, hp);
+            H.hit = (int)(r & 1u); H.k = (int)((r >> 1) & 3u); H.sk = (r & 8u) ? -1 : 1;
+            H.hx = hp[0]; H.hy = hp[1]; H.hz = hp[2]; H.work = 0;
+        }
+        work = H.work;
+        hit = H.hit != 0;
+        if (hit) {
+            const float nk = (float)(-H.sk);
+            s_org[0][tid] = H.hx + (H.k == 0 ? nk : 0.0f) * 1e-3f;
+            s_org[1][tid] = H.hy + (H.k == 1 ? nk : 0.0f) * 1e-3f;
+            s_org[2][tid] = H.hz + (H.k == 2 ? nk : 0.0f) * 1e-3f;
+            s_face[tid] = (unsigned char)(2 * H.k + (H.sk < 0 ? 1 : 0));
+            // direction classes: ray j + 1 has elevation sqrt(1 - u1) over its surface, u1 = (hash >> 8) * 2^-24
+            // (secondary_dir): class = the top four bits of u1, counted from the shallow end
+            unsigned hsh = pcg_hash(0x5EEDu ^ (row * P.w + col));
+            bins = SEC_BINS - 1;  // the shadow ray
+            for (unsigned j = 0; j < 4; ++j) {
+                bins |= (15u - (hsh >> 28)) << (5u * (j + 1u));
+                hsh = pcg_hash(hsh); hsh = pcg_hash(hsh);
+            }
+            for (unsigned j = 0; j < 5; ++j) atomicAdd(&s_count[(bins >> (5u * j)) & 31u], 1u);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned run = 0;
+        for (unsigned b = 0; b < SEC_BINS; ++b) { s_base[b] = run; run += s_count[b]; }
+        s_total = run;
+    }
+    __syncthreads();
+    if (hit)
+        for (unsigned j = 0; j < 5; ++j) {
+            const unsigned at = atomicAdd(&s_base[(bins >> (5u * j)) & 31u], 1u);
+            s_ray[at] = (unsigned short)(tid | (j << 8));
+        }
+    __syncthreads();
+
+    // ---- phase 2: every wavefront traces rays of the list until it is empty.  A lane whose ray has ended
+    // takes the next ray of the list as soon as SEC_REFILL lanes of its wavefront are free (one LDS ticket for
+    // all of them, ranks by mbcnt over the ballot of free lanes), so a wavefront's trips stay filled while
+    // rays of very different lengths -- three trips on average, a hundred at most -- come and go.  Every
+    // wavefront sees the list empty sooner or later and leaves the loop, so all reach the barrier below.
+    const unsigned total = s_total;
+    {
+        const int lox = P.lo[0], loy = P.lo[1], loz = P.lo[2], upx = P.up[0], upy = P.up[1], upz = P.up[2];
+        const TraceParams *params = (const TraceParams *)__builtin_amdgcn_kernarg_segment_ptr();
+        const unsigned lane = tid & 63u;
+        CellRay<T, FORM == FORM_POW2> ray;
+        ray.idle();
+        unsigned mine = 0;      // pixel | ray index << 8 of the ray this lane holds
+        unsigned trips = 0;     // wave uniform: trips of the traversal loop this wavefront ran
+        bool     drained = false;  // wave uniform: the list has no ray left for this wavefront
+        for (;;) {
+            const unsigned long long free_lanes = __ballot(ray.live ? 0 : 1);
+            const unsigned nfree = (unsigned)__popcll(free_lanes);
+            if (!drained && nfree >= SEC_REFILL) {
+                unsigned first = 0;
+                if (lane == 0) first = atomicAdd(&s_next, nfree);
+                first = (unsigned)__builtin_amdgcn_readfirstlane((int)first);
+                drained = first + nfree >= total;
+                const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(free_lanes >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)free_lanes, 0u));
+                if (!ray.live && first + rank < total) {
+                    mine = s_ray[first + rank];
+                    const unsigned pix = mine & 255u, j = mine >> 8;
+                    unsigned pcol, pq, prow;
+                    pixel_of_thread(P, by, pix, pcol, pq, prow);
+                    float sdx, sdy, sdz;
+                    secondary_dir(prow * P.w + pcol, j, (int)s_face[pix], sdx, sdy, sdz);
+                    const float sox = s_org[0][pix], soy = s_org[1][pix], soz = s_org[2][pix];
+                    if (FORM == FORM_CAPPED) {  // the one-step-per-trip form is not resumable: the whole ray here
+                        RayHit S;
+                        traverse_skip<T>(P, sox, soy, soz, sdx, sdy, sdz, lox, loy, loz, upx, upy, upz, S);
+                        atomicAdd(&s_steps[pix], S.steps);
+                        if (S.hit) atomicAdd(&s_hits[pix], j == 0 ? 1u : 256u);
+                    } else if (ray_is_regular(sdx, sdy, sdz)) {
+                        ray.template begin<false>(P, sox, soy, soz, sdx, sdy, sdz, lox, loy, loz, f2i_small(floorf(sox)),
+                                                  f2i_small(floorf(soy)), f2i_small(floorf(soz)), 0u);
+                        if (!ray.live) atomicAdd(&s_steps[pix], ray.steps_done());  // starts outside the loaded area
+                    } else {
+                        const unsigned r = degenerate_ray<T, FORM>(params, sox, soy, soz, sdx, sdy, sdz);
+                        atomicAdd(&s_steps[pix], r & 0x7fffffffu);
+                        if (r >> 31) atomicAdd(&s_hits[pix], j == 0 ? 1u : 256u);
+                    }
+                }
+            }
+            if (!__any(ray.live ? 1 : 0)) {
+                if (drained) break;
+                continue;  // every lane is free: the next round refills them
+            }
+            trips += 1u;
+            if (ray.live) {
+                ray.trip(P);
+                if (!ray.live) {  // ended in this trip: its result goes to its pixel
+                    const unsigned pix = mine & 255u;
+                    atomicAdd(&s_steps[pix], ray.steps_done());
+                    if (ray.hit) atomicAdd(&s_hits[pix], (mine >> 8) == 0 ? 1u : 256u);
+                }
+            }
+        }
+        work += trips;
+    }
+    __syncthreads();
+
+    // ---- phase 3: every lane stores its own pixel
+    if (inside) {
+        const size_t i = (size_t)q * P.w + col;
+        if (shadow) shadow[i] = (uint8_t)(s_hits[tid] & 1u);
+        if (ao) ao[i] = (uint8_t)(s_hits[tid] >> 8);
+        if (sec_steps) sec_steps[i] = s_steps[tid];
+    }
+    if (P.sched.cost) {
+        sched_end(P, by, work);
         const unsigned first = blockIdx.y * gridDim.x + blockIdx.x;
         if (first < gridDim.y && threadIdx.x < 64) {
             sched_reduce_row(P, first);
@@ -1106,18 +1313,23 @@ hipError_t launch_trace_literal(const TraceParams &p, int voxel_bytes, hipStream
     return hipGetLastError();
 }
 
-hipError_t launch_trace_secondary(const TraceParams &p, int voxel_bytes, uint8_t *shadow, uint8_t *ao,
+hipError_t launch_trace_secondary(const TraceParams &p, int voxel_bytes, bool binned, uint8_t *shadow, uint8_t *ao,
                                   uint32_t *sec_steps, hipStream_t s)
 {
     if (p.rows.rows == 0 || p.w == 0) return hipSuccess;
     const dim3 grid = trace_grid(p), block(256);
     const int form = trace_form(p);
-#define VRT_LAUNCH_SECONDARY(T)                                                                              \
-    (form == FORM_CAPPED ? k_trace_secondary<T, FORM_CAPPED><<<grid, block, 0, s>>>(p, shadow, ao, sec_steps) \
-     : form == FORM_POW2 ? k_trace_secondary<T, FORM_POW2><<<grid, block, 0, s>>>(p, shadow, ao, sec_steps)   \
-                         : k_trace_secondary<T, FORM_ANY_N><<<grid, block, 0, s>>>(p, shadow, ao, sec_steps))
-    if (voxel_bytes == 1) VRT_LAUNCH_SECONDARY(uint8_t);
-    else VRT_LAUNCH_SECONDARY(uint16_t);
+#define VRT_LAUNCH_SECONDARY(K, T)                                                           \
+    (form == FORM_CAPPED ? K<T, FORM_CAPPED><<<grid, block, 0, s>>>(p, shadow, ao, sec_steps) \
+     : form == FORM_POW2 ? K<T, FORM_POW2><<<grid, block, 0, s>>>(p, shadow, ao, sec_steps)   \
+                         : K<T, FORM_ANY_N><<<grid, block, 0, s>>>(p, shadow, ao, sec_steps))
+    if (binned) {
+        if (voxel_bytes == 1) VRT_LAUNCH_SECONDARY(k_trace_secondary_binned, uint8_t);
+        else VRT_LAUNCH_SECONDARY(k_trace_secondary_binned, uint16_t);
+    } else {
+        if (voxel_bytes == 1) VRT_LAUNCH_SECONDARY(k_trace_secondary, uint8_t);
+        else VRT_LAUNCH_SECONDARY(k_trace_secondary, uint16_t);
+    }
 #undef VRT_LAUNCH_SECONDARY
     return hipGetLastError();
 }

@@ -1140,6 +1140,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     __shared__ unsigned       s_steps[256];    // loop iterations summed over the pixel's rays
     __shared__ unsigned       s_hits[256];     // bit 0: the shadow ray hit; bits 8..: ambient-occlusion rays that hit
     __shared__ unsigned short s_ray[5 * 256];  // the sorted list: pixel | ray index << 8
+    __shared__ float          s_dir[3][4 * 256];  // directions of the ambient-occlusion rays, by position in the list
     __shared__ unsigned       s_count[SEC_BINS], s_base[SEC_BINS], s_next, s_total;
 
     const unsigned tid = threadIdx.x;
@@ -1204,17 +1205,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             s_ray[at] = (unsigned short)(tid | (j << 8));
         }
     __syncthreads();
+    // the directions of the ambient-occlusion rays (all of the list but its tail of shadow rays), worked out by all
+    // 256 lanes side by side rather than by whichever lanes are free when a ray is drawn
+    const unsigned total = s_total, n_ao = total - s_count[SEC_BINS - 1];
+    for (unsigned at = tid; at < n_ao; at += 256u) {
+        const unsigned rec = s_ray[at], pix = rec & 255u;
+        unsigned pcol, pq, prow;
+        pixel_of_thread(P, by, pix, pcol, pq, prow);
+        float dx, dy, dz;
+        secondary_dir(prow * P.w + pcol, rec >> 8, (int)s_face[pix], dx, dy, dz);
+        s_dir[0][at] = dx; s_dir[1][at] = dy; s_dir[2][at] = dz;
+    }
+    __syncthreads();
 
     // ---- phase 2: every wavefront traces rays of the list until it is empty.  A lane whose ray has ended
     // takes the next ray of the list as soon as SEC_REFILL lanes of its wavefront are free (one LDS ticket for
     // all of them, ranks by mbcnt over the ballot of free lanes), so a wavefront's trips stay filled while
     // rays of very different lengths -- three trips on average, a hundred at most -- come and go.  Every
     // wavefront sees the list empty sooner or later and leaves the loop, so all reach the barrier below.
-    const unsigned total = s_total;
     {
         const int lox = P.lo[0], loy = P.lo[1], loz = P.lo[2], upx = P.up[0], upy = P.up[1], upz = P.up[2];
         const TraceParams *params = (const TraceParams *)__builtin_amdgcn_kernarg_segment_ptr();
         const unsigned lane = tid & 63u;
+        float lightx, lighty, lightz;
+        secondary_dir(0u, 0u, 0, lightx, lighty, lightz);  // the shadow rays' one direction
         CellRay<T, FORM == FORM_POW2> ray;
         ray.idle();
         unsigned mine = 0;      // pixel | ray index << 8 of the ray this lane holds
@@ -1230,12 +1244,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 drained = first + nfree >= total;
                 const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(free_lanes >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)free_lanes, 0u));
                 if (!ray.live && first + rank < total) {
-                    mine = s_ray[first + rank];
+                    const unsigned at = first + rank;
+                    mine = s_ray[at];
                     const unsigned pix = mine & 255u, j = mine >> 8;
-                    unsigned pcol, pq, prow;
-                    pixel_of_thread(P, by, pix, pcol, pq, prow);
-                    float sdx, sdy, sdz;
-                    secondary_dir(prow * P.w + pcol, j, (int)s_face[pix], sdx, sdy, sdz);
+                    const unsigned dat = min(at, 4u * 256u - 1u);
+                    const float sdx = at < n_ao ? s_dir[0][dat] : lightx, sdy = at < n_ao ? s_dir[1][dat] : lighty,
+                                sdz = at < n_ao ? s_dir[2][dat] : lightz;
                     const float sox = s_org[0][pix], soy = s_org[1][pix], soz = s_org[2][pix];
                     if (FORM == FORM_CAPPED) {  // the one-step-per-trip form is not resumable: the whole ray here
                         RayHit S;
@@ -1271,8 +1285,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     }
     __syncthreads();
 
-    // ---- phase 3: every lane stores its own pixel
-    if (inside) {
+    // ---- phase 3: every lane stores its own pixel (coordinates worked out again rather than kept across the phases)
+    if (pixel_of_thread(P, by, opaque(tid), col, q, row)) {
         const size_t i = (size_t)q * P.w + col;
         if (shadow) shadow[i] = (uint8_t)(s_hits[tid] & 1u);
         if (ao) ao[i] = (uint8_t)(s_hits[tid] >> 8);

@@ -1130,10 +1130,13 @@ constexpr unsigned SEC_BINS = 17;  // 16 elevation classes of ambient-occlusion 
 #ifndef VRT_SEC_REFILL
 #define VRT_SEC_REFILL 24
 #endif
+#ifndef VRT_SEC_WAVES
+#define VRT_SEC_WAVES 8
+#endif
 constexpr unsigned SEC_REFILL = VRT_SEC_REFILL;  // free lanes at which a wavefront draws new rays (1..64; 64: whole bundles)
 
 template <typename T, int FORM>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_trace_secondary_binned(const TraceParams P, uint8_t *shadow, uint8_t *ao, uint32_t *sec_steps)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VRT_SEC_WAVES, 8))) void k_trace_secondary_binned(const TraceParams P, uint8_t *shadow, uint8_t *ao, uint32_t *sec_steps)
 {
     __shared__ float          s_org[3][256];   // origin of the pixel's secondary rays
     __shared__ unsigned char  s_face[256];     // face of the primary hit, 0xff: no hit

@@ -75,6 +75,11 @@ typedef struct vrt_outputs {
     float    *rgba;         /* 4 per pixel, the shader's colour before the UNORM store */
 } vrt_outputs;
 
+/* Measurement knobs, read from the environment once per vrt_create and meant for A/B runs only (none changes a
+ * pixel): VRT_TILE_LOG2H=k (wavefront tile of (64 >> k) x (1 << k) pixels instead of 16 x 4), VRT_NO_ROW_ORDER=1
+ * (workgroup rows always top to bottom), VRT_ROW_BLOCK0=r (always start at workgroup row r), VRT_SCHED_DEBUG=1
+ * (print what each launch measured; synchronises), VRT_SECONDARY=pixel (vrt_trace_secondary without the LDS
+ * binning); vrt_comm_create reads VRT_COMM_SELF_SENDRECV=1 (the root's own part through RCCL as well). */
 /* ≙ GraphicsCore::new (src/graphics/mod.rs:292-425), minus window/swapchain:
  * picks the device, creates the stream, allocates the N^3 world images. */
 int vrt_create(const vrt_config *cfg, vrt_ctx **out);
@@ -158,6 +163,30 @@ uint32_t vrt_strip_rows(uint32_t h, uint32_t strip_h, uint32_t part, uint32_t pa
 int vrt_assemble_strips(vrt_ctx *ctx, const void *gathered, void *frame, uint32_t row_bytes, uint32_t h,
                         uint32_t strip_h, uint32_t parts, uint32_t part_stride_rows);
 
+/* ---- several GPUs driven by ONE process: the framebuffer exchange ------------------------------------------
+ * The reference picks one physical device (src/graphics/mod.rs:325-342) and has no counterpart.  A host that
+ * shards a frame (vrt_trace_strips) or a batch of poses over n GPUs creates one context per HIP device, each
+ * holding a replica of the world, and one communicator over them: RCCL, one rank per context in the order given
+ * (ncclCommInitAll); RCCL is loaded when the first communicator is created and a machine without it gets
+ * VRT_E_UNSUPPORTED.  Context 0 is the root, the one that receives.  Both gathers are one group of ncclSend /
+ * ncclRecv enqueued on the contexts' own streams -- behind the traces enqueued there before, no host wait -- and
+ * a device copy for the root's own part; vrt_sync(ctxs[0]) waits for the result.  Buffers are DEVICE memory of
+ * the context they belong to.  (A host with one process per GPU gathers with its own collective and calls
+ * vrt_assemble_strips.) */
+typedef struct vrt_comm vrt_comm;
+int vrt_comm_create(vrt_ctx *const *ctxs, uint32_t n, vrt_comm **out);  /* n = 1..64 contexts on distinct devices */
+int vrt_comm_destroy(vrt_comm *comm);                                   /* waits for the contexts' streams */
+uint32_t vrt_comm_size(const vrt_comm *comm);
+/* bytes_each bytes at send[i] (context i's device) -> recv_root + i * bytes_each (root's device): whole frames of
+ * a pose-sharded batch. */
+int vrt_gather(vrt_comm *comm, const void *const *send, size_t bytes_each, void *recv_root);
+/* A strip-sharded frame: packed[i] holds the vrt_strip_rows(h, strip_h, i, n) rows context i traced as part i of
+ * n (vrt_trace_strips), row_bytes each.  They are gathered into `gathered` (n * part_stride_rows rows, root's
+ * device; part_stride_rows at least the largest part's row count) and put back in image order into `frame` (h
+ * rows, root's device) as vrt_assemble_strips does. */
+int vrt_gather_strips(vrt_comm *comm, const void *const *packed, void *gathered, void *frame, uint32_t row_bytes,
+                      uint32_t h, uint32_t strip_h, uint32_t part_stride_rows);
+
 /* Page-locked host memory for HOST output planes (and for worlds handed to vrt_upload_world): copies
  * between it and the device run at the bus rate, about three times the rate of pageable memory
  * (1080p BGRA8 frame, kernel + copy: 0.23 ms against 0.54 ms).  Any host memory is accepted by the
@@ -184,8 +213,10 @@ int vrt_kernel_time_sampling(vrt_ctx *ctx, uint32_t every_n);
 /* Name of the kernel the last vrt_trace launched ("literal" or "skip"). */
 const char *vrt_last_kernel_name(vrt_ctx *ctx);
 
-/* The context's hipStream_t, for callers that enqueue their own work behind a trace. */
+/* The context's hipStream_t, for callers that enqueue their own work behind a trace, and its HIP device ordinal
+ * (-1 for a null context). */
 void *vrt_stream(vrt_ctx *ctx);
+int vrt_device(vrt_ctx *ctx);
 
 const char *vrt_last_error(void);
 const char *vrt_version(void);

@@ -72,6 +72,13 @@ SYMBOLS = {
     "vrt_kernel_time_sampling": (C.c_int, [_CTX, C.c_uint32]),
     "vrt_last_kernel_name": (C.c_char_p, [_CTX]),
     "vrt_stream": (C.c_void_p, [_CTX]),
+    "vrt_device": (C.c_int, [_CTX]),
+    "vrt_comm_create": (C.c_int, [C.POINTER(_CTX), C.c_uint32, C.POINTER(C.c_void_p)]),
+    "vrt_comm_destroy": (C.c_int, [C.c_void_p]),
+    "vrt_comm_size": (C.c_uint32, [C.c_void_p]),
+    "vrt_gather": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.c_void_p]),
+    "vrt_gather_strips": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                    C.c_uint32, C.c_uint32]),
     "vrt_last_error": (C.c_char_p, []),
     "vrt_version": (C.c_char_p, []),
 }

@@ -111,6 +111,15 @@ int static_scratch_for(int device, Scratch **out)
 
 }  // namespace
 
+int vrt::set_error(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
 struct vrt_ctx {
     int         device       = 0;
     hipStream_t stream       = nullptr;
@@ -755,5 +764,6 @@ int vrt_kernel_time_sampling(vrt_ctx *c, uint32_t every_n)
 
 const char *vrt_last_kernel_name(vrt_ctx *c) { return c ? c->last_kernel : "none"; }
 void *vrt_stream(vrt_ctx *c) { return c ? (void *)c->stream : nullptr; }
+int vrt_device(vrt_ctx *c) { return c ? c->device : -1; }
 
 }  // extern "C"

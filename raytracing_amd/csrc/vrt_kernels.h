@@ -7,6 +7,9 @@
 
 namespace vrt {
 
+// Records the thread's error message (vrt_last_error) and returns `code`; shared by the files of the C ABI.
+int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
 // Which rows a launch covers.  Packed row q of the output planes maps to image row
 //   row(q) = y0 + q                                   (strip_h == 0: plain band)
 //   row(q) = ((q / strip_h) * parts + part) * strip_h + q % strip_h   (interleaved strips)

@@ -86,3 +86,41 @@ def gather_frame(packed, h, strip_h, dst=0, group=None, out=None, core=None, pad
         return frame
     dist.gather(buf, None, dst=dst, group=group)
     return None
+
+
+class Comm:
+    """Several GPUs driven by this one process: `cores` are GraphicsCore objects on distinct HIP devices, the
+    first one the root.  A thin wrapper of vrt_comm_create / vrt_gather / vrt_gather_strips (RCCL send / receive
+    enqueued on the cores' own streams); buffers are device addresses."""
+
+    def __init__(self, cores):
+        import ctypes as C
+        from . import _lib as L
+        self._L, self._C = L, C
+        self.cores = list(cores)
+        arr = (C.c_void_p * len(self.cores))(*[c._ctx for c in self.cores])
+        self._comm = C.c_void_p()
+        L.check(L.lib().vrt_comm_create(arr, len(self.cores), C.byref(self._comm)))
+
+    def size(self):
+        return self._L.lib().vrt_comm_size(self._comm)
+
+    def gather(self, send_ptrs, bytes_each, recv_root_ptr):
+        arr = (self._C.c_void_p * len(send_ptrs))(*send_ptrs)
+        self._L.check(self._L.lib().vrt_gather(self._comm, arr, bytes_each, recv_root_ptr))
+
+    def gather_strips(self, packed_ptrs, gathered_ptr, frame_ptr, row_bytes, h, strip_h, part_stride_rows):
+        arr = (self._C.c_void_p * len(packed_ptrs))(*packed_ptrs)
+        self._L.check(self._L.lib().vrt_gather_strips(self._comm, arr, gathered_ptr, frame_ptr, row_bytes, h, strip_h,
+                                                      part_stride_rows))
+
+    def close(self):
+        if self._comm:
+            self._L.lib().vrt_comm_destroy(self._comm)
+            self._comm = self._C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

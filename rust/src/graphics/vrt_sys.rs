@@ -8,6 +8,11 @@ pub struct VrtCtx {
 }
 
 #[repr(C)]
+pub struct VrtComm {
+    _private: [u8; 0],
+}
+
+#[repr(C)]
 pub struct VrtConfig {
     pub struct_size: u32,
     pub device: i32,
@@ -68,6 +73,12 @@ extern "C" {
     pub fn vrt_kernel_time_sampling(ctx: *mut VrtCtx, every_n: u32) -> c_int;
     pub fn vrt_last_kernel_name(ctx: *mut VrtCtx) -> *const c_char;
     pub fn vrt_stream(ctx: *mut VrtCtx) -> *mut c_void;
+    pub fn vrt_device(ctx: *mut VrtCtx) -> c_int;
+    pub fn vrt_comm_create(ctxs: *const *mut VrtCtx, n: u32, out: *mut *mut VrtComm) -> c_int;
+    pub fn vrt_comm_destroy(comm: *mut VrtComm) -> c_int;
+    pub fn vrt_comm_size(comm: *const VrtComm) -> u32;
+    pub fn vrt_gather(comm: *mut VrtComm, send: *const *const c_void, bytes_each: usize, recv_root: *mut c_void) -> c_int;
+    pub fn vrt_gather_strips(comm: *mut VrtComm, packed: *const *const c_void, gathered: *mut c_void, frame: *mut c_void, row_bytes: u32, h: u32, strip_h: u32, part_stride_rows: u32) -> c_int;
     pub fn vrt_last_error() -> *const c_char;
     pub fn vrt_version() -> *const c_char;
 }

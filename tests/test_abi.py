@@ -55,6 +55,24 @@ def test_argument_validation_without_a_device():
     assert lib.vrt_sync(None) == L.VRT_E_INVALID_ARG
 
 
+def test_communicator_argument_validation_without_a_device():
+    # every check that precedes RCCL: null arguments, rank counts, null contexts, null communicators
+    lib = L.lib()
+    comm = C.c_void_p()
+    assert lib.vrt_comm_create(None, 1, C.byref(comm)) == L.VRT_E_INVALID_ARG
+    one = (C.c_void_p * 1)(None)
+    assert lib.vrt_comm_create(one, 1, None) == L.VRT_E_INVALID_ARG
+    assert lib.vrt_comm_create(one, 0, C.byref(comm)) == L.VRT_E_INVALID_ARG
+    assert lib.vrt_comm_create(one, 65, C.byref(comm)) == L.VRT_E_INVALID_ARG
+    assert lib.vrt_comm_create(one, 1, C.byref(comm)) == L.VRT_E_INVALID_ARG and b"context 0 is null" in lib.vrt_last_error()
+    assert not comm.value
+    assert lib.vrt_comm_destroy(None) == L.VRT_OK
+    assert lib.vrt_comm_size(None) == 0
+    assert lib.vrt_gather(None, one, 16, None) == L.VRT_E_INVALID_ARG
+    assert lib.vrt_gather_strips(None, one, None, None, 16, 16, 8, 16) == L.VRT_E_INVALID_ARG
+    assert lib.vrt_device(None) == -1
+
+
 def test_strip_rows_partition():
     lib = L.lib()
     for h, sh, parts in [(2160, 16, 8), (1080, 8, 4), (480, 16, 3), (48, 16, 2)]:

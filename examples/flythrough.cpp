@@ -6,7 +6,7 @@
 //
 // Prints the camera transform of the last frame (16 floats, column major) and an FNV-1a hash
 // of its B8G8R8A8 frame; optionally writes the raw frame.
-#include "../include/graphics_core.hpp"
+#include "game_logic.hpp"
 
 #include <cstdlib>
 #include <fstream>

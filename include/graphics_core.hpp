@@ -8,9 +8,9 @@
 //   GraphicsCore   src/graphics/mod.rs:134-148,150-183,245-291,292-428,430-475,531-634
 //   PushConstants  src/graphics/push_constants.rs:4-9
 //   GraphicsSettings src/graphics/graphics_settings.rs:1-17
-//   Player         src/game_logic/player/mod.rs:5-64
-//   KeyStates      src/game_logic/key_states.rs:4-35
-//   GameState      src/game_logic/game_state.rs:10-89
+//
+// The callers' own code (Player, KeyStates, GameState of src/game_logic) is not part of this interface; a C++
+// rendering of it, used by the example and its test, lives in examples/game_logic.hpp.
 //
 // What is NOT mirrored: window, swapchain, event loop and input devices (presentation, not
 // part of this path).  `GraphicsCore::run` therefore takes a frame count and an optional
@@ -26,8 +26,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
-#include <functional>
-#include <set>
+#include <cstddef>
+#include <type_traits>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -92,20 +92,6 @@ struct GraphicsSettings {  // graphics_settings.rs:9-16
     float   mouse_sensitivity[2] = {0.002f, 0.002f};
 };
 
-enum class VirtualKeyCode { W, A, S, D, Space, LShift, T, R, Escape };
-
-struct KeyStates {  // key_states.rs:4-35
-    std::set<VirtualKeyCode> currently_pressed, new_pressed;
-    void update(VirtualKeyCode key, bool pressed)
-    {
-        if (pressed) { if (currently_pressed.insert(key).second) new_pressed.insert(key); }
-        else currently_pressed.erase(key);
-    }
-    void reset() { new_pressed.clear(); }
-};
-
-class GameState;
-
 // Stands in for `Option<Box<dyn GpuFuture>>` (src/graphics/mod.rs:140): game_state.rs:77 calls
 // previous_frame_end.take().unwrap().then_signal_fence_and_flush().unwrap().wait(None).unwrap().
 struct FrameToken {
@@ -151,7 +137,9 @@ public:
     GraphicsSettings get_settings() const { return settings_; }  // mod.rs:426-428
 
     // mod.rs:245-291
-    void upload_chunk_gpu(Vector3i chunk_pos, GameState &) { check(vrt_generate_chunk(ctx_, chunk_pos.x, chunk_pos.y, chunk_pos.z)); }
+    // (the reference passes its GameState along and does not use it; any type will do)
+    template <class GameStateT>
+    void upload_chunk_gpu(Vector3i chunk_pos, GameStateT &) { check(vrt_generate_chunk(ctx_, chunk_pos.x, chunk_pos.y, chunk_pos.z)); }
     // mod.rs:150-183
     void reset_distance_field() { check(vrt_reset_distance_field(ctx_)); }
 
@@ -169,8 +157,18 @@ public:
 
     // mod.rs:430-475 without the OS event loop: `frames` redraws; `input` is called before each
     // frame in place of the window/device events the reference feeds into game_state.
-    void run(GameState &game_state, const std::function<PushConstants(GraphicsCore &, GameState &)> &game_update,
-             uint32_t frames, const std::function<void(uint32_t, GameState &)> &input = nullptr);
+    // GameStateT is the caller's game state (the reference's GameState, src/game_logic/game_state.rs; a C++
+    // rendering of it lives in examples/game_logic.hpp); the loop touches its `key_states.reset()` only.
+    template <class GameStateT, class GameUpdate, class Input = std::nullptr_t>
+    void run(GameStateT &game_state, GameUpdate &&game_update, uint32_t frames, Input &&input = nullptr)
+    {
+        for (uint32_t f = 0; f < frames; ++f) {
+            if constexpr (!std::is_same_v<std::decay_t<Input>, std::nullptr_t>) input(f, game_state);  // ≙ keyboard / mouse events (mod.rs:437-454)
+            const PushConstants pc = game_update(*this, game_state);  // ≙ RedrawEventsCleared (mod.rs:467-471)
+            if (redraw(pc)) continue;
+            game_state.key_states.reset();
+        }
+    }
 
     void resize(uint32_t width, uint32_t height)  // ≙ WindowEvent::Resized -> recreate_swapchain
     {
@@ -212,108 +210,5 @@ private:
     uint32_t             width_, height_;
     Frame                frame_;
 };
-
-class Player {  // player/mod.rs:5-64
-public:
-    static constexpr float BASE_SPEED = 0.02f;
-    float look_direction[2] = {0.0f, 0.0f};  // (yaw, pitch)
-
-    static Player spawn() { return Player(); }
-    Matrix4  get_transform() const { return matrix_; }
-    Vector3f get_position() const { return {matrix_.at(0, 3), matrix_.at(1, 3), matrix_.at(2, 3)}; }
-    void     set_position(Vector3f p) { matrix_.at(0, 3) = p.x; matrix_.at(1, 3) = p.y; matrix_.at(2, 3) = p.z; }
-    void apply_rotation()  // :25-30  matrix = T * Rx(pitch) * Ry(yaw)
-    {
-        reset_rotation();
-        const Matrix4 transform = Matrix4::from_scaled_axis({look_direction[1], 0, 0}) * Matrix4::from_scaled_axis({0, look_direction[0], 0});
-        matrix_ = matrix_ * transform;
-    }
-    void update_pos(const std::set<VirtualKeyCode> &keys, float speed_modifier)  // :37-63
-    {
-        const float yaw = look_direction[0];
-        const Vector3f forward{-std::sin(yaw), 0.0f, std::cos(yaw)}, right{std::cos(yaw), 0.0f, std::sin(yaw)}, up{0, 1, 0};
-        Vector3f mov;
-        auto add = [&](Vector3f v, float s) { mov.x += s * v.x; mov.y += s * v.y; mov.z += s * v.z; };
-        if (keys.count(VirtualKeyCode::W)) add(forward, 1);
-        if (keys.count(VirtualKeyCode::A)) add(right, -1);
-        if (keys.count(VirtualKeyCode::S)) add(forward, -1);
-        if (keys.count(VirtualKeyCode::D)) add(right, 1);
-        if (keys.count(VirtualKeyCode::Space)) add(up, 1);
-        if (keys.count(VirtualKeyCode::LShift)) add(up, -1);
-        const float cap = BASE_SPEED * speed_modifier;
-        const float norm = std::sqrt(mov.x * mov.x + mov.y * mov.y + mov.z * mov.z);
-        if (norm > cap) { const float s = cap / norm; mov.x *= s; mov.y *= s; mov.z *= s; }  // cap_magnitude
-        matrix_.at(0, 3) += mov.x; matrix_.at(1, 3) += mov.y; matrix_.at(2, 3) += mov.z;      // append_translation_mut
-    }
-
-private:
-    void reset_rotation()  // :32-36
-    {
-        const Vector3f t = get_position();
-        matrix_ = Matrix4::identity();
-        set_position(t);
-    }
-    Matrix4 matrix_ = Matrix4::identity();
-};
-
-class GameState {  // game_state.rs:10-89
-public:
-    Player    player = Player::spawn();
-    KeyStates key_states;
-    float     speed_modifier = 1.0f;
-
-    explicit GameState(GraphicsCore &render_core) { upload_chunks_around_player(render_core, nullptr); }  // :27-39
-
-    Vector3i current_player_chunk() const  // :20-22
-    {
-        const Vector3f p = player.get_position();
-        const float cs = (float)GraphicsCore::CHUNK_SIZE;
-        return {(int32_t)std::floor(p.x / cs), (int32_t)std::floor(p.y / cs), (int32_t)std::floor(p.z / cs)};
-    }
-    void player_look_dir(double dx, double dy, const float sens[2])  // :23-26
-    {
-        player.look_direction[0] = player.look_direction[0] - (float)dx * sens[0];
-        player.look_direction[1] = std::min(1.7f, std::max(-1.7f, player.look_direction[1] - (float)dy * sens[1]));
-    }
-    void update_player(float speed, GraphicsCore &render_core)  // :41-48
-    {
-        const Vector3i old_chunk = current_player_chunk();
-        player.apply_rotation();
-        player.update_pos(key_states.currently_pressed, speed);
-        upload_chunks_around_player(render_core, &old_chunk);
-    }
-    // :50-83; returns the number of chunks regenerated
-    int upload_chunks_around_player(GraphicsCore &core, const Vector3i *old_chunk)
-    {
-        const Vector3i new_chunk = current_player_chunk();
-        if (old_chunk && (new_chunk - *old_chunk).amax() == 0) return 0;
-        const int gen_dist = (int)core.get_settings().render_distance + 1;
-        int count = 0;
-        for (int x = -gen_dist; x <= gen_dist; ++x)
-            for (int y = -gen_dist; y <= gen_dist; ++y)
-                for (int z = -gen_dist; z <= gen_dist; ++z) {
-                    const Vector3i chunk_position = new_chunk + Vector3i{x, y, z};
-                    if (old_chunk && (chunk_position - *old_chunk).amax() <= gen_dist) continue;
-                    core.upload_chunk_gpu(chunk_position, *this);
-                    ++count;
-                }
-        core.previous_frame_end.then_signal_fence_and_flush().wait();  // :77
-        core.reset_distance_field();                                    // :82
-        return count;
-    }
-    Matrix4 get_player_transform() const { return player.get_transform(); }  // :86-88
-};
-
-inline void GraphicsCore::run(GameState &game_state,
-                              const std::function<PushConstants(GraphicsCore &, GameState &)> &game_update,
-                              uint32_t frames, const std::function<void(uint32_t, GameState &)> &input)
-{
-    for (uint32_t f = 0; f < frames; ++f) {
-        if (input) input(f, game_state);                 // ≙ keyboard / mouse events (mod.rs:437-454)
-        const PushConstants pc = game_update(*this, game_state);  // ≙ RedrawEventsCleared (mod.rs:467-471)
-        if (redraw(pc)) continue;
-        game_state.key_states.reset();
-    }
-}
 
 }  // namespace tube

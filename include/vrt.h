@@ -95,6 +95,11 @@ int vrt_upload_world(vrt_ctx *ctx, const void *block, const void *dist, uint32_t
  * terrain generator (terrain_gen.comp:14-24, noise.glsl) for the 32^3 voxels of one chunk
  * and store them at their toroidal texels. */
 int vrt_generate_chunk(vrt_ctx *ctx, int32_t cx, int32_t cy, int32_t cz);
+/* The same for `count` chunks at chunk positions (xyz[3*i], xyz[3*i+1], xyz[3*i+2]), 64 chunks per launch: what a
+ * caller that collects the chunk positions of one GameState::upload_chunks_around_player pass
+ * (src/game_logic/game_state.rs:61-75) hands over in one call (a crossing at grid_n = 1056 regenerates 1089
+ * chunks: 17 ms of launches one by one, 18 launches this way). */
+int vrt_generate_chunks(vrt_ctx *ctx, const int32_t *xyz, uint32_t count);
 
 /* The same generator for every world voxel of the cube [wmin, wmin+n)^3 in one launch
  * (what GameState::upload_chunks_around_player, src/game_logic/game_state.rs:50-83,
@@ -104,7 +109,10 @@ int vrt_generate_window(vrt_ctx *ctx, const int32_t wmin[3]);
 /* ≙ GraphicsCore::reset_distance_field (src/graphics/mod.rs:150-183): clears the distance
  * image to zero.  Also the point at which the traversal's own skip structure is rebuilt
  * after world edits (the reference calls it after every batch of chunk uploads,
- * game_state.rs:82). */
+ * game_state.rs:82).  After vrt_generate_chunk calls on an indexed world the rebuild is incremental: the regenerated
+ * chunks' cells and the cells within 31 cells of them, whose empty-space distances can see them; after
+ * vrt_upload_world or vrt_generate_window it covers the whole grid.  Launches only, no allocation after the first
+ * build, no host wait. */
 int vrt_reset_distance_field(vrt_ctx *ctx);
 
 /* ≙ the compute dispatch inside GraphicsCore::redraw (src/graphics/mod.rs:581-597) with
@@ -200,6 +208,13 @@ int vrt_sync(vrt_ctx *ctx);
 
 /* Copy the block image back (tests of the generator).  `block_out`: n^3 texels. */
 int vrt_download_world(vrt_ctx *ctx, void *block_out, uint32_t memory);
+
+/* Copy the traversal index out (tests of its builders; the reference has no such structure): `cells_out`, (n/4)^3
+ * records of 16 bytes -- the 64-bit occupancy mask of a 4^3 cell, bit z*16 + y*4 + x, then its eight octant
+ * distances -- and `pyr_out`, (n/4)^3 x 16 bytes of column-top pyramid entries as levelled for the window of the
+ * last trace (VRT_E_UNSUPPORTED before the first trace after a world change); either may be NULL.  The index is
+ * brought up to date with the voxel image first, as vrt_reset_distance_field does. */
+int vrt_download_index(vrt_ctx *ctx, void *cells_out, void *pyr_out, uint32_t memory);
 
 /* HIP-event time of the trace kernel: sum and count over all vrt_trace calls since the
  * last vrt_kernel_time_reset.  Waits for the stream. */

@@ -52,6 +52,7 @@ SYMBOLS = {
     "vrt_destroy": (C.c_int, [_CTX]),
     "vrt_upload_world": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]),
     "vrt_generate_chunk": (C.c_int, [_CTX, C.c_int32, C.c_int32, C.c_int32]),
+    "vrt_generate_chunks": (C.c_int, [_CTX, C.POINTER(C.c_int32), C.c_uint32]),
     "vrt_generate_window": (C.c_int, [_CTX, C.POINTER(C.c_int32)]),
     "vrt_reset_distance_field": (C.c_int, [_CTX]),
     "vrt_trace": (C.c_int, [_CTX, _F, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(VrtOutputs)]),
@@ -67,6 +68,7 @@ SYMBOLS = {
     "vrt_free_host": (C.c_int, [_CTX, C.c_void_p]),
     "vrt_sync": (C.c_int, [_CTX]),
     "vrt_download_world": (C.c_int, [_CTX, C.c_void_p, C.c_uint32]),
+    "vrt_download_index": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_uint32]),
     "vrt_kernel_time": (C.c_int, [_CTX, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "vrt_kernel_time_reset": (C.c_int, [_CTX]),
     "vrt_kernel_time_sampling": (C.c_int, [_CTX, C.c_uint32]),

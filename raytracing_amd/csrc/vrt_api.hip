@@ -137,7 +137,11 @@ struct vrt_ctx {
     uint4      *d_cells      = nullptr;  // (n/4)^3 records: occupancy mask + octant distances
     uint16_t   *d_tops       = nullptr;  // column-top pyramid scratch, 2 * (n/4)^2
     uint4      *d_pyr        = nullptr;  // (n/4)^3 x 16 B: column-top pyramid at voxel precision
-    uint8_t    *d_build      = nullptr;  // 11 x (n/4)^3 B: intermediates of the octant distance passes, kept between builds
+    uint8_t    *d_build      = nullptr;  // 6 x (n/4)^3 B: the x and y planes of the octant distance transform, kept between builds
+    // what the skip structure has not seen yet: nothing (skip_valid), a box of regenerated chunks, or everything
+    bool        index_built  = false;    // records and planes describe some earlier state of the whole voxel image
+    bool        dirty_box    = false;    // chunks inside [dirty_lo, dirty_hi) (world cells of 4^3 voxels) changed since
+    int32_t     dirty_lo[3]  = {0, 0, 0}, dirty_hi[3] = {0, 0, 0};
     Scratch     own;                     // per-frame tables + dispatch-order slots of this context
     uint64_t    serial       = 0;        // distinguishes contexts in the dispatch-order history of a shared scratch
     int         pyr_offcy    = -1;       // vertical window offset (cells) the pyramid entries were built for
@@ -194,9 +198,25 @@ int ensure_skip_structure(vrt_ctx *c, int offcy)
         if (!c->d_cells) HIP_TRY(hipMalloc(&c->d_cells, cells(c) * sizeof(uint4)));
         if (!c->d_tops) HIP_TRY(hipMalloc(&c->d_tops, 2 * (size_t)(c->n / 4) * (c->n / 4) * sizeof(uint16_t)));
         if (!c->d_pyr) HIP_TRY(hipMalloc(&c->d_pyr, cells(c) * sizeof(uint4)));
-        if (!c->d_build) HIP_TRY(hipMalloc(&c->d_build, 11 * cells(c)));  // the separable distance passes' intermediates
-        HIP_TRY(vrt::launch_build_cells(c->d_block, c->voxel_bytes, (int)c->n, c->d_cells, c->d_build, c->stream));
+        if (!c->d_build) HIP_TRY(hipMalloc(&c->d_build, 6 * cells(c)));
+        const int nc = (int)c->n / 4;
+        if (c->index_built && c->dirty_box) {
+            // only regenerated chunks since the last build: their cells, and the cells whose distances see them
+            int origin[3], extent[3];
+            for (int k = 0; k < 3; ++k) {
+                const int64_t len = (int64_t)c->dirty_hi[k] - c->dirty_lo[k];
+                if (len >= nc) { origin[k] = 0; extent[k] = nc; continue; }
+                int o = c->dirty_lo[k] % nc;
+                origin[k] = o < 0 ? o + nc : o;
+                extent[k] = (int)len;
+            }
+            HIP_TRY(vrt::launch_update_cells(c->d_block, c->voxel_bytes, (int)c->n, c->d_cells, c->d_build, origin, extent, c->stream));
+        } else {
+            HIP_TRY(vrt::launch_build_cells(c->d_block, c->voxel_bytes, (int)c->n, c->d_cells, c->d_build, c->stream));
+        }
         c->skip_valid = true;
+        c->index_built = true;
+        c->dirty_box = false;
         c->pyr_offcy = -1;
     }
     if (offcy >= 0 && c->pyr_offcy != offcy) {
@@ -204,6 +224,28 @@ int ensure_skip_structure(vrt_ctx *c, int offcy)
         c->pyr_offcy = offcy;
     }
     return VRT_OK;
+}
+
+// the voxel image changed everywhere (or nobody knows where): the next build is a whole one
+void world_replaced(vrt_ctx *c)
+{
+    c->have_world = true;
+    c->skip_valid = false;
+    c->index_built = false;
+    c->dirty_box = false;
+}
+
+// the voxels of world box [lo, lo + len) changed (voxel coordinates, multiples of 4)
+void world_box_changed(vrt_ctx *c, const int32_t lo[3], int32_t len)
+{
+    c->have_world = true;
+    c->skip_valid = false;
+    for (int k = 0; k < 3; ++k) {
+        const int32_t a = lo[k] >> 2, b = (lo[k] + len) >> 2;  // arithmetic shift: floor for negative coordinates
+        if (!c->dirty_box) { c->dirty_lo[k] = a; c->dirty_hi[k] = b; }
+        else { c->dirty_lo[k] = std::min(c->dirty_lo[k], a); c->dirty_hi[k] = std::max(c->dirty_hi[k], b); }
+    }
+    c->dirty_box = true;
 }
 
 // vertical offset (in cells) of the loaded window for a camera at height y (raytrace.glsl:19-24)
@@ -530,24 +572,31 @@ int vrt_upload_world(vrt_ctx *c, const void *block, const void *dist, uint32_t n
     } else {
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
-    c->have_world = true;
-    c->skip_valid = false;
+    world_replaced(c);
+    return VRT_OK;
+}
+
+int vrt_generate_chunks(vrt_ctx *c, const int32_t *xyz, uint32_t count)
+{
+    if (!c || (!xyz && count)) return fail(VRT_E_INVALID_ARG, "null argument");
+    if (c->n < VRT_CHUNK_SIZE) return fail(VRT_E_UNSUPPORTED, "grid_n smaller than one chunk");
+    const int32_t lim = (1 << 20) / VRT_CHUNK_SIZE;
+    for (uint32_t i = 0; i < 3 * count; ++i)
+        if (xyz[i] < -lim || xyz[i] > lim) return fail(VRT_E_INVALID_ARG, "chunk position beyond +/-2^20 voxels");
+    if (count == 0) return VRT_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(vrt::launch_terrain_chunks(c->d_block, c->voxel_bytes, (int)c->n, xyz, count, c->stream));
+    for (uint32_t i = 0; i < count; ++i) {
+        const int32_t lo[3] = {xyz[3 * i] * VRT_CHUNK_SIZE, xyz[3 * i + 1] * VRT_CHUNK_SIZE, xyz[3 * i + 2] * VRT_CHUNK_SIZE};
+        world_box_changed(c, lo, VRT_CHUNK_SIZE);
+    }
     return VRT_OK;
 }
 
 int vrt_generate_chunk(vrt_ctx *c, int32_t cx, int32_t cy, int32_t cz)
 {
-    if (!c) return fail(VRT_E_INVALID_ARG, "null argument");
-    if (c->n < VRT_CHUNK_SIZE) return fail(VRT_E_UNSUPPORTED, "grid_n smaller than one chunk");
-    const int32_t lim = (1 << 20) / VRT_CHUNK_SIZE;
-    if (cx < -lim || cx > lim || cy < -lim || cy > lim || cz < -lim || cz > lim)
-        return fail(VRT_E_INVALID_ARG, "chunk position beyond +/-2^20 voxels");
-    HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(vrt::launch_terrain(c->d_block, c->voxel_bytes, (int)c->n, cx * VRT_CHUNK_SIZE, cy * VRT_CHUNK_SIZE,
-                                cz * VRT_CHUNK_SIZE, VRT_CHUNK_SIZE, VRT_CHUNK_SIZE, VRT_CHUNK_SIZE, c->stream));
-    c->have_world = true;
-    c->skip_valid = false;
-    return VRT_OK;
+    const int32_t xyz[3] = {cx, cy, cz};
+    return vrt_generate_chunks(c, xyz, 1);
 }
 
 int vrt_generate_window(vrt_ctx *c, const int32_t wmin[3])
@@ -558,8 +607,7 @@ int vrt_generate_window(vrt_ctx *c, const int32_t wmin[3])
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(vrt::launch_terrain(c->d_block, c->voxel_bytes, (int)c->n, wmin[0], wmin[1], wmin[2], (int)c->n, (int)c->n,
                                 (int)c->n, c->stream));
-    c->have_world = true;
-    c->skip_valid = false;
+    world_replaced(c);
     return VRT_OK;
 }
 
@@ -729,6 +777,22 @@ int vrt_download_world(vrt_ctx *c, void *block_out, uint32_t memory)
     HIP_TRY(hipSetDevice(c->device));
     const hipMemcpyKind kind = memory == VRT_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
     HIP_TRY(hipMemcpyAsync(block_out, c->d_block, texels(c) * (size_t)c->voxel_bytes, kind, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return VRT_OK;
+}
+
+int vrt_download_index(vrt_ctx *c, void *cells_out, void *pyr_out, uint32_t memory)
+{
+    if (!c) return fail(VRT_E_INVALID_ARG, "null argument");
+    if (memory != VRT_MEM_HOST && memory != VRT_MEM_DEVICE) return fail(VRT_E_INVALID_ARG, "bad memory kind");
+    if (!c->have_world) return fail(VRT_E_NO_WORLD, "no world uploaded or generated");
+    if (c->dist_nonzero) return fail(VRT_E_UNSUPPORTED, "a world with a non-zero distance image has no traversal index");
+    HIP_TRY(hipSetDevice(c->device));
+    { int rc = ensure_skip_structure(c, -1); if (rc != VRT_OK) return rc; }
+    if (pyr_out && c->pyr_offcy < 0) return fail(VRT_E_UNSUPPORTED, "the column-top pyramid is levelled by the first trace after a world change");
+    const hipMemcpyKind kind = memory == VRT_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    if (cells_out) HIP_TRY(hipMemcpyAsync(cells_out, c->d_cells, cells(c) * sizeof(uint4), kind, c->stream));
+    if (pyr_out) HIP_TRY(hipMemcpyAsync(pyr_out, c->d_pyr, cells(c) * sizeof(uint4), kind, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return VRT_OK;
 }

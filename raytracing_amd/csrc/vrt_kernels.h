@@ -99,8 +99,15 @@ hipError_t launch_trace_secondary(const TraceParams &p, int voxel_bytes, bool bi
 // world kernels
 hipError_t launch_terrain(void *block, int voxel_bytes, int n, int x0, int y0, int z0,
                           int ex, int ey, int ez, hipStream_t s);
-// cells = nc^3 records; tmp = 11 * nc^3 bytes of scratch
-hipError_t launch_build_cells(const void *block, int voxel_bytes, int n, uint4 *cells, uint8_t *tmp, hipStream_t s);
+// `count` chunks of 32^3 voxels at chunk positions xyz[3 * i ..] (host memory), 64 chunks per launch
+hipError_t launch_terrain_chunks(void *block, int voxel_bytes, int n, const int32_t *xyz, uint32_t count, hipStream_t s);
+// cells = nc^3 records; planes = 6 * nc^3 bytes: the x and y planes of the separable octant distance transform,
+// which must keep their contents between a build and the updates that follow it
+hipError_t launch_build_cells(const void *block, int voxel_bytes, int n, uint4 *cells, uint8_t *planes, hipStream_t s);
+// The same for the cells whose voxels changed, a box of the torus (origin in [0, nc), extent 1..nc per axis), and
+// for every cell around it whose distances depend on them.
+hipError_t launch_update_cells(const void *block, int voxel_bytes, int n, uint4 *cells, uint8_t *planes, const int origin[3],
+                               const int extent[3], hipStream_t s);
 // tops: scratch of at least 2 * nc * nc uint16_t; offcy = rem_euclid(lower_y, n) / 4; pyr = nc^3 records
 hipError_t launch_build_voxel_pyramid(const uint4 *cells, int nc, int offcy, uint16_t *tops, uint4 *pyr, hipStream_t s);
 hipError_t launch_frame_tables(float *ncx, float *ncy, float *sin2, uint32_t w, uint32_t h, float ncy_off,

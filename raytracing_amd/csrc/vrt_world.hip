@@ -4,9 +4,9 @@
 //                     stored at their toroidal texels (bit-exact restatement: same
 //                     operation order as the shader, no FMA contraction).
 //   k_cell_masks    : one 64-bit occupancy mask per 4^3 cell of the texel image.
-//   k_df_dir_pass   : one axis of the separable (min, max) octant distance transform over
-//                     cells (torus metric); x, y, z passes per direction octant.
-//   k_pack_dist     : the eight octant distances of a cell into its 16-byte record.
+//   k_df_x, k_df_y, k_df_z_pack : the separable (min, max) octant distance transform over cells (torus
+//                     metric), both directions of an axis per launch; the last packs the eight octant
+//                     distances of a cell into its 16-byte record.  All of these run on a box of cells.
 //   k_column_vtops, k_tops_reduce, k_voxel_pyramid : the column-top pyramid at voxel precision,
 //                     one 16-byte record per cell next to the cell records.
 //   k_any_nonzero   : is the uploaded distance image all zero (as shipped)?
@@ -125,6 +125,46 @@ __global__ __launch_bounds__(256) void k_terrain(T *block, int n, int x0, int y0
     block[(tz * (size_t)n + ty) * (size_t)n + tx] = v;
 }
 
+// the same for up to 64 chunks of 32^3 voxels per launch (positions in chunk units): a workgroup is 32 x 8 voxels
+// of one chunk, so every lane of a wavefront has a voxel
+struct ChunkBatch {
+    int count;
+    int xyz[64][3];
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_terrain_chunks(T *block, int n, ChunkBatch batch)
+{
+    const int *c = batch.xyz[blockIdx.x];
+    const int px = c[0] * 32 + (int)(threadIdx.x & 31u);
+    const int py = c[1] * 32 + (int)(blockIdx.y * 8u + (threadIdx.x >> 5));
+    const int pz = c[2] * 32 + (int)blockIdx.z;
+    T v;
+    if (py > 128 || py < -128) {  // see k_terrain
+        v = py < 0 ? (T)1 : (T)0;
+    } else {
+        const float noise_val = snoise((float)px * 0.015f, (float)py * 0.015f, (float)pz * 0.015f) * 6.0f - (float)py;
+        v = noise_val > 0.0f ? (T)1 : (T)0;
+    }
+    const size_t tx = (size_t)rem_euclid(px, n), ty = (size_t)rem_euclid(py, n), tz = (size_t)rem_euclid(pz, n);
+    block[(tz * (size_t)n + ty) * (size_t)n + tx] = v;
+}
+
+hipError_t launch_terrain_chunks(void *block, int voxel_bytes, int n, const int32_t *xyz, uint32_t count, hipStream_t s)
+{
+    for (uint32_t done = 0; done < count;) {
+        ChunkBatch b;
+        b.count = (int)(count - done < 64u ? count - done : 64u);
+        for (int i = 0; i < b.count; ++i)
+            for (int k = 0; k < 3; ++k) b.xyz[i][k] = xyz[3 * (done + (uint32_t)i) + (uint32_t)k];
+        const dim3 grid((unsigned)b.count, 4, 32), blockdim(256);
+        if (voxel_bytes == 1) k_terrain_chunks<uint8_t><<<grid, blockdim, 0, s>>>((uint8_t *)block, n, b);
+        else k_terrain_chunks<uint16_t><<<grid, blockdim, 0, s>>>((uint16_t *)block, n, b);
+        done += (uint32_t)b.count;
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_terrain(void *block, int voxel_bytes, int n, int x0, int y0, int z0, int ex, int ey, int ez,
                           hipStream_t s)
 {
@@ -139,14 +179,31 @@ hipError_t launch_terrain(void *block, int voxel_bytes, int n, int x0, int y0, i
 // ---------------------------------------------------------------------------
 // cell records: cell (cx,cy,cz) covers texels [4c, 4c+4)^3
 // ---------------------------------------------------------------------------
-// occupancy mask, bit = z*16 + y*4 + x; the distance word is filled by k_pack_dist
-template <typename T>
-__global__ __launch_bounds__(256) void k_cell_masks(const T *block, int n, int nc, uint4 *cells)
+// Every builder below works on a box of cells of the torus: origin o (each coordinate in [0, nc)) and extent e
+// (1..nc per axis); the cell of a thread is (o + local) mod nc.  The whole torus is the box (0, nc); after a few
+// chunks have been regenerated only the cells whose records can have changed are visited (launch_update_cells).
+struct CellBox {
+    int ox, oy, oz, ex, ey, ez;
+};
+
+VRT_DEV bool box_cell(const CellBox &b, int nc, int &cx, int &cy, int &cz)
 {
-    const int cx = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int cy = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int cz = blockIdx.z;
-    if (cx >= nc || cy >= nc) return;
+    const int lx = blockIdx.x * 64 + (threadIdx.x & 63), ly = blockIdx.y * 4 + (threadIdx.x >> 6), lz = blockIdx.z;
+    if (lx >= b.ex || ly >= b.ey || lz >= b.ez) return false;
+    cx = b.ox + lx; cx -= cx >= nc ? nc : 0;
+    cy = b.oy + ly; cy -= cy >= nc ? nc : 0;
+    cz = b.oz + lz; cz -= cz >= nc ? nc : 0;
+    return true;
+}
+
+static dim3 box_grid(const CellBox &b) { return dim3((b.ex + 63) / 64, (b.ey + 3) / 4, b.ez); }
+
+// occupancy mask, bit = z*16 + y*4 + x; the distance words are filled by k_df_z_pack
+template <typename T>
+__global__ __launch_bounds__(256) void k_cell_masks(const T *block, int n, int nc, CellBox box, uint4 *cells)
+{
+    int cx, cy, cz;
+    if (!box_cell(box, nc, cx, cy, cz)) return;
     uint64_t m = 0;
 #pragma unroll
     for (int z = 0; z < 4; ++z) {
@@ -164,81 +221,119 @@ __global__ __launch_bounds__(256) void k_cell_masks(const T *block, int n, int n
             m |= (uint64_t)bits << (z * 16 + y * 4);
         }
     }
-    cells[((size_t)cz * nc + cy) * nc + cx] = make_uint4((unsigned)m, (unsigned)(m >> 32), 0u, 0u);
+    uint2 *dst = reinterpret_cast<uint2 *>(cells + ((size_t)cz * nc + cy) * nc + cx);
+    *dst = make_uint2((unsigned)m, (unsigned)(m >> 32));
 }
 
-// One axis of the octant transform: out(p) = min over r >= 0 of max(r, in(p + dir*r)) along
-// `axis` (torus).  Applied along x, y, z with directions (sx, sy, sz) to in = {0 non-empty,
-// CAP empty} it yields the Chebyshev distance to the nearest non-empty cell q with
-// s_k*(q_k - c_k) >= 0 on every axis, i.e. the side of the largest empty cube of cells that
-// has the cell at its corner and extends into that octant, capped at DF_CAP cells: wide open space is
-// the column-top pyramid's job, and a pass costs up to DF_CAP look-ups per cell (1024^3 voxels:
-// 8.5 ms of passes with a cap of 255, 2.5 ms with 32, same trace times).
+// The octant distances come from a separable transform.  One axis of it: out(p) = min over r >= 0 of
+// max(r, in(p + dir*r)) along the axis (torus).  Applied along x, y, z with directions (sx, sy, sz) to
+// in = {0 non-empty, CAP empty} it yields the Chebyshev distance to the nearest non-empty cell q with
+// s_k*(q_k - c_k) >= 0 on every axis, i.e. the side of the largest empty cube of cells that has the cell at its
+// corner and extends into that octant, capped at DF_CAP cells: wide open space is the column-top pyramid's
+// job, and a pass costs up to DF_CAP look-ups per cell and direction (1024^3 voxels: 8.5 ms of passes with a
+// cap of 255, 2.5 ms with 32, same trace times).  Three launches: x (both directions from the masks, two
+// planes), y (both directions of both x planes, four planes), z (both directions of the four y planes, the eight
+// results packed straight into the record).  The x and y planes stay in memory between builds: a value depends
+// on the DF_CAP - 1 cells ahead of it only, so after a change inside a box of cells the x planes are redone on
+// the box widened by DF_CAP - 1 cells along x, the y planes on that widened along y, the records on that widened
+// along z, and every other cell keeps a value that is still right.
 constexpr int DF_CAP = 32;
-template <bool FROM_CELLS>
-__global__ __launch_bounds__(256) void k_df_dir_pass(const uint4 *cells, const uint8_t *in, uint8_t *out, int nc,
-                                                     int axis, int dir)
+
+template <typename LOAD>
+VRT_DEV int df_scan(LOAD value, int self, int pos, int nc, int dir)
 {
-    const int cx = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int cy = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int cz = blockIdx.z;
-    if (cx >= nc || cy >= nc) return;
-    const size_t self = ((size_t)cz * nc + cy) * nc + cx;
-    auto value = [&](size_t i) -> int {
-        if (FROM_CELLS) {
-            const uint2 m = *reinterpret_cast<const uint2 *>(cells + i);
-            return (m.x | m.y) != 0 ? 0 : DF_CAP;
-        }
-        return (int)in[i];
-    };
-    const int    pos    = axis == 0 ? cx : (axis == 1 ? cy : cz);
-    const size_t stride = axis == 0 ? 1 : (axis == 1 ? (size_t)nc : (size_t)nc * nc);
-    const size_t line   = self - (size_t)pos * stride;
-    int best = value(self);
+    int best = self;
     for (int r = 1; r < best && r < nc; ++r) {
         int q = pos + dir * r;
         q += q < 0 ? nc : 0;
         q -= q >= nc ? nc : 0;
-        best = min(best, max(r, value(line + (size_t)q * stride)));
+        best = min(best, max(r, value(q)));
     }
-    out[self] = (uint8_t)best;
+    return best;
 }
 
-// gather the eight octant fields into the distance word of each record
-__global__ __launch_bounds__(256) void k_pack_dist(const uint8_t *oct, size_t ncells, uint4 *cells)
+// planes: tx[sx] at tx + sx * ncells
+__global__ __launch_bounds__(256) void k_df_x(const uint4 *cells, int nc, CellBox box, uint8_t *tx)
 {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= ncells) return;
+    int cx, cy, cz;
+    if (!box_cell(box, nc, cx, cy, cz)) return;
+    const size_t ncells = (size_t)nc * nc * nc, line = ((size_t)cz * nc + cy) * nc;
+    auto value = [&](int q) -> int {
+        const uint2 m = *reinterpret_cast<const uint2 *>(cells + line + q);
+        return (m.x | m.y) != 0 ? 0 : DF_CAP;
+    };
+    const int self = value(cx);
+    tx[line + cx]          = (uint8_t)df_scan(value, self, cx, nc, -1);
+    tx[ncells + line + cx] = (uint8_t)df_scan(value, self, cx, nc, 1);
+}
+
+// planes: ty[sx | sy << 1] at ty + (sx | sy << 1) * ncells
+__global__ __launch_bounds__(256) void k_df_y(const uint8_t *tx, int nc, CellBox box, uint8_t *ty)
+{
+    int cx, cy, cz;
+    if (!box_cell(box, nc, cx, cy, cz)) return;
+    const size_t ncells = (size_t)nc * nc * nc, base = (size_t)cz * nc * nc + cx;
+#pragma unroll
+    for (int sx = 0; sx < 2; ++sx) {
+        const uint8_t *in = tx + (size_t)sx * ncells + base;
+        auto value = [&](int q) -> int { return (int)in[(size_t)q * nc]; };
+        const int self = value(cy);
+        ty[(size_t)sx * ncells + base + (size_t)cy * nc]       = (uint8_t)df_scan(value, self, cy, nc, -1);
+        ty[(size_t)(sx | 2) * ncells + base + (size_t)cy * nc] = (uint8_t)df_scan(value, self, cy, nc, 1);
+    }
+}
+
+// the eight octant distances of a cell, byte o = sx | sy << 1 | sz << 2, into the record's .z and .w words
+__global__ __launch_bounds__(256) void k_df_z_pack(const uint8_t *ty, int nc, CellBox box, uint4 *cells)
+{
+    int cx, cy, cz;
+    if (!box_cell(box, nc, cx, cy, cz)) return;
+    const size_t ncells = (size_t)nc * nc * nc, plane = (size_t)nc * nc, base = (size_t)cy * nc + cx;
     unsigned lo = 0, hi = 0;
 #pragma unroll
-    for (int o = 0; o < 4; ++o) {
-        lo |= (unsigned)oct[(size_t)o * ncells + i] << (8 * o);
-        hi |= (unsigned)oct[(size_t)(o + 4) * ncells + i] << (8 * o);
+    for (int sxy = 0; sxy < 4; ++sxy) {
+        const uint8_t *in = ty + (size_t)sxy * ncells + base;
+        auto value = [&](int q) -> int { return (int)in[(size_t)q * plane]; };
+        const int self = value(cz);
+        lo |= (unsigned)df_scan(value, self, cz, nc, -1) << (8 * sxy);
+        hi |= (unsigned)df_scan(value, self, cz, nc, 1) << (8 * sxy);
     }
-    uint2 *dst = reinterpret_cast<uint2 *>(cells + i) + 1;
+    uint2 *dst = reinterpret_cast<uint2 *>(cells + (size_t)cz * plane + base) + 1;
     *dst = make_uint2(lo, hi);
 }
 
-hipError_t launch_build_cells(const void *block, int voxel_bytes, int n, uint4 *cells, uint8_t *tmp, hipStream_t s)
+// box [lo, lo + len) of an axis widened by `grow` cells on both sides, on a torus of nc cells
+static void widen(int &o, int &e, int grow, int nc)
 {
-    const int    nc = n / 4;
-    const dim3   grid((nc + 63) / 64, (nc + 3) / 4, nc), blockdim(256);
+    if (e + 2 * grow >= nc) { o = 0; e = nc; return; }
+    o -= grow; e += 2 * grow;
+    o %= nc; if (o < 0) o += nc;
+}
+
+hipError_t launch_update_cells(const void *block, int voxel_bytes, int n, uint4 *cells, uint8_t *planes, const int origin[3],
+                               const int extent[3], hipStream_t s)
+{
+    const int nc = n / 4;
+    CellBox b{origin[0], origin[1], origin[2], extent[0], extent[1], extent[2]};
+    if (b.ex <= 0 || b.ey <= 0 || b.ez <= 0) return hipSuccess;
     const size_t ncells = (size_t)nc * nc * nc;
-    if (voxel_bytes == 1) k_cell_masks<uint8_t><<<grid, blockdim, 0, s>>>((const uint8_t *)block, n, nc, cells);
-    else k_cell_masks<uint16_t><<<grid, blockdim, 0, s>>>((const uint16_t *)block, n, nc, cells);
-    uint8_t *tx = tmp, *ty0 = tmp + ncells, *ty1 = tmp + 2 * ncells, *oct = tmp + 3 * ncells;
-    for (int sx = 0; sx < 2; ++sx) {
-        k_df_dir_pass<true><<<grid, blockdim, 0, s>>>(cells, nullptr, tx, nc, 0, sx ? 1 : -1);
-        k_df_dir_pass<false><<<grid, blockdim, 0, s>>>(nullptr, tx, ty0, nc, 1, -1);
-        k_df_dir_pass<false><<<grid, blockdim, 0, s>>>(nullptr, tx, ty1, nc, 1, 1);
-        for (int sy = 0; sy < 2; ++sy)
-            for (int sz = 0; sz < 2; ++sz)
-                k_df_dir_pass<false><<<grid, blockdim, 0, s>>>(nullptr, sy ? ty1 : ty0,
-                                                               oct + (size_t)(sx | (sy << 1) | (sz << 2)) * ncells, nc, 2,
-                                                               sz ? 1 : -1);
-    }
-    k_pack_dist<<<(unsigned)((ncells + 255) / 256), 256, 0, s>>>(oct, ncells, cells);
+    const dim3 blockdim(256);
+    if (voxel_bytes == 1) k_cell_masks<uint8_t><<<box_grid(b), blockdim, 0, s>>>((const uint8_t *)block, n, nc, b, cells);
+    else k_cell_masks<uint16_t><<<box_grid(b), blockdim, 0, s>>>((const uint16_t *)block, n, nc, b, cells);
+    uint8_t *tx = planes, *ty = planes + 2 * ncells;
+    widen(b.ox, b.ex, DF_CAP - 1, nc);
+    k_df_x<<<box_grid(b), blockdim, 0, s>>>(cells, nc, b, tx);
+    widen(b.oy, b.ey, DF_CAP - 1, nc);
+    k_df_y<<<box_grid(b), blockdim, 0, s>>>(tx, nc, b, ty);
+    widen(b.oz, b.ez, DF_CAP - 1, nc);
+    k_df_z_pack<<<box_grid(b), blockdim, 0, s>>>(ty, nc, b, cells);
     return hipGetLastError();
+}
+
+hipError_t launch_build_cells(const void *block, int voxel_bytes, int n, uint4 *cells, uint8_t *planes, hipStream_t s)
+{
+    const int origin[3] = {0, 0, 0}, extent[3] = {n / 4, n / 4, n / 4};
+    return launch_update_cells(block, voxel_bytes, n, cells, planes, origin, extent, s);
 }
 
 // ---------------------------------------------------------------------------

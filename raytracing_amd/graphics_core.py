@@ -108,7 +108,13 @@ class GraphicsCore:
         cam = push_constants.column_major() if isinstance(push_constants, PushConstants) else push_constants
         return self.trace(cam, self.width, self.height, outputs=outputs)
 
-    def upload_chunks_around_player(self, position, old_chunk=None):
+    def upload_chunks_gpu(self, chunk_positions):
+        """vrt_generate_chunks: a batch of chunks, 64 per launch."""
+        flat = [int(v) for cp in chunk_positions for v in cp]
+        if flat:
+            L.check(L.lib().vrt_generate_chunks(self._ctx, (C.c_int32 * len(flat))(*flat), len(flat) // 3))
+
+    def upload_chunks_around_player(self, position, old_chunk=None, batched=False):
         """The caller-side policy of GameState::upload_chunks_around_player
         (src/game_logic/game_state.rs:50-83), provided for tests of the seam: regenerate
         the chunks that entered the (2*gen_dist+1)^3 window, then reset the distance field."""
@@ -117,14 +123,19 @@ class GraphicsCore:
             return 0
         gen_dist = self.settings.render_distance + 1
         count = 0
+        batch = []
         for x in range(-gen_dist, gen_dist + 1):
             for y in range(-gen_dist, gen_dist + 1):
                 for z in range(-gen_dist, gen_dist + 1):
                     cp = (new_chunk[0] + x, new_chunk[1] + y, new_chunk[2] + z)
                     if old_chunk is not None and max(abs(a - b) for a, b in zip(cp, old_chunk)) <= gen_dist:
                         continue
-                    self.upload_chunk_gpu(cp)
+                    if batched:
+                        batch.append(cp)
+                    else:
+                        self.upload_chunk_gpu(cp)
                     count += 1
+        self.upload_chunks_gpu(batch)
         self.sync()
         self.reset_distance_field()
         return count
@@ -151,6 +162,15 @@ class GraphicsCore:
         out = np.empty((self.grid_n,) * 3, self.voxel_dtype)
         L.check(L.lib().vrt_download_world(self._ctx, out.ctypes.data, L.MEM_HOST))
         return out
+
+    def download_index(self, pyramid=False):
+        """The traversal index as the device holds it: cell records, and optionally the column-top pyramid words,
+        each (n/4)^3 x 4 uint32.  Brings the index up to date first."""
+        nc = self.grid_n // 4
+        cells = np.empty((nc ** 3, 4), np.uint32)
+        pyr = np.empty((nc ** 3, 4), np.uint32) if pyramid else None
+        L.check(L.lib().vrt_download_index(self._ctx, cells.ctypes.data, pyr.ctypes.data if pyramid else None, L.MEM_HOST))
+        return (cells, pyr) if pyramid else cells
 
     def _cam(self, cam):
         cam = np.ascontiguousarray(cam, dtype=np.float32).reshape(16)

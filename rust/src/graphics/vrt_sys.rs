@@ -56,6 +56,7 @@ extern "C" {
     pub fn vrt_destroy(ctx: *mut VrtCtx) -> c_int;
     pub fn vrt_upload_world(ctx: *mut VrtCtx, block: *const c_void, dist: *const c_void, n: u32, memory: u32) -> c_int;
     pub fn vrt_generate_chunk(ctx: *mut VrtCtx, cx: i32, cy: i32, cz: i32) -> c_int;
+    pub fn vrt_generate_chunks(ctx: *mut VrtCtx, xyz: *const i32, count: u32) -> c_int;
     pub fn vrt_generate_window(ctx: *mut VrtCtx, wmin: *const i32) -> c_int;
     pub fn vrt_reset_distance_field(ctx: *mut VrtCtx) -> c_int;
     pub fn vrt_trace(ctx: *mut VrtCtx, cam_col_major: *const f32, w: u32, h: u32, y0: u32, y1: u32, out: *const VrtOutputs) -> c_int;
@@ -68,6 +69,7 @@ extern "C" {
     pub fn vrt_free_host(ctx: *mut VrtCtx, ptr: *mut c_void) -> c_int;
     pub fn vrt_sync(ctx: *mut VrtCtx) -> c_int;
     pub fn vrt_download_world(ctx: *mut VrtCtx, block_out: *mut c_void, memory: u32) -> c_int;
+    pub fn vrt_download_index(ctx: *mut VrtCtx, cells_out: *mut c_void, pyr_out: *mut c_void, memory: u32) -> c_int;
     pub fn vrt_kernel_time(ctx: *mut VrtCtx, total_ms: *mut f64, launches: *mut u64) -> c_int;
     pub fn vrt_kernel_time_reset(ctx: *mut VrtCtx) -> c_int;
     pub fn vrt_kernel_time_sampling(ctx: *mut VrtCtx, every_n: u32) -> c_int;

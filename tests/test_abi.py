@@ -53,6 +53,8 @@ def test_argument_validation_without_a_device():
     assert lib.vrt_create(C.byref(cfg), C.byref(ctx)) == L.VRT_E_INVALID_ARG
     assert lib.vrt_destroy(None) == L.VRT_OK
     assert lib.vrt_sync(None) == L.VRT_E_INVALID_ARG
+    assert lib.vrt_generate_chunks(None, None, 0) == L.VRT_E_INVALID_ARG
+    assert lib.vrt_download_index(None, None, None, 0) == L.VRT_E_INVALID_ARG
 
 
 def test_communicator_argument_validation_without_a_device():

@@ -77,3 +77,46 @@ def test_generator_far_from_the_surface_matches_oracle():
             assert got[z % n, y % n, x % n] == want, (x, y, z)
     # whole layers: solid below, air above
     assert got[:, (-200) % n, :].all() and not got[:, 200 % n, :].any()
+
+
+@pytest.mark.parametrize("render_distance", [1, 3, 6])  # grids of 160, 288 and 480 voxels: 40, 72 and 120 cells per axis
+def test_index_updated_chunk_by_chunk_equals_an_index_built_whole(render_distance):
+    """After a chunk crossing only the regenerated chunks' cells and the cells within 31 cells of them are
+    re-indexed (on the 160 grid that is everything, on the 288 grid a box that wraps round the torus, on the 480
+    grid a slab).  Every record, and every pyramid word after a trace from the new position, must equal those of
+    a context that was handed the same voxels whole; the frames of both must be equal on every plane."""
+    from raytracing_amd import GraphicsSettings, Player
+    n = 32 * (2 * render_distance + 3)
+    walk = [(0.0, 10.0, 0.0), (33.0, 10.0, 0.0), (33.0, 10.0, -1.0), (33.0, -2.0, -1.0), (70.0, -2.0, -1.0),
+            (100.0, 33.0, -40.0),   # two chunks in x, one in y, one in z at once
+            (100.0, 33.0, -40.0 - 32.0 * (2 * render_distance + 4)),  # further than the window is wide: every chunk is new
+            (60.0, 33.0, -40.0 - 32.0 * (2 * render_distance + 4))]
+    planes = ("bgra8", "voxel", "face", "steps", "t")
+    with GraphicsCore(settings=GraphicsSettings(render_distance=render_distance), trace_mode=TRACE_SKIP) as g, \
+         GraphicsCore(settings=GraphicsSettings(render_distance=render_distance), trace_mode=TRACE_SKIP) as fresh:
+        assert g.grid_n == n
+        old = None
+        for i, pos in enumerate(walk):
+            count = g.upload_chunks_around_player(pos, old, batched=i % 2 == 1)  # chunk by chunk, or 64 chunks per launch
+            old = tuple(int(np.floor(v / 32.0)) for v in pos)
+            assert i == 0 or count > 0
+            fresh.upload_world(g.download_world())
+            fresh.reset_distance_field()
+            cam = scenes.cam16(Player.at(pos, 0.3 + 0.9 * i, -0.35))
+            a = g.trace(cam, 320, 240, outputs=planes)
+            b = fresh.trace(cam, 320, 240, outputs=planes)
+            for k in planes:
+                assert np.array_equal(a[k].view(np.uint32) if a[k].dtype == np.float32 else a[k],
+                                      b[k].view(np.uint32) if b[k].dtype == np.float32 else b[k]), (i, k)
+            ca, pa = g.download_index(pyramid=True)
+            cb, pb = fresh.download_index(pyramid=True)
+            assert np.array_equal(ca, cb), (i, int((ca != cb).any(axis=1).sum()))
+            assert np.array_equal(pa, pb), (i, int((pa != pb).any(axis=1).sum()))
+        # the walk ends on frames the oracle agrees with (the 160 grid is small enough for it)
+        if n == 160:
+            full = O.trace(O.World(g.download_world()), cam, 320, 240)
+            for k in planes:
+                x, y = a[k], full[k]
+                if x.dtype == np.float32:
+                    x, y = x.view(np.uint32), y.view(np.uint32)
+                assert np.array_equal(x, y), k

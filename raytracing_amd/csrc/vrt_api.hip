@@ -134,9 +134,9 @@ struct vrt_ctx {
     bool        dist_nonzero = false;
     bool        have_world   = false;
     // skip structure
-    uint4      *d_cells      = nullptr;  // (n/4)^3 records: occupancy mask + octant distances
+    uint4      *d_cells      = nullptr;  // (n/4)^3 x 32 B: per cell the record (occupancy mask + octant distances), then its pyramid words
     uint16_t   *d_tops       = nullptr;  // column-top pyramid scratch, 2 * (n/4)^2
-    uint4      *d_pyr        = nullptr;  // (n/4)^3 x 16 B: column-top pyramid at voxel precision
+    uint4      *d_pyr        = nullptr;  // d_cells + 1: column-top pyramid at voxel precision, cell i's words at d_pyr[2 * i]
     uint8_t    *d_build      = nullptr;  // 6 x (n/4)^3 B: the x and y planes of the octant distance transform, kept between builds
     // what the skip structure has not seen yet: nothing (skip_valid), a box of regenerated chunks, or everything
     bool        index_built  = false;    // records and planes describe some earlier state of the whole voxel image
@@ -195,9 +195,8 @@ int drain_events(vrt_ctx *c)
 int ensure_skip_structure(vrt_ctx *c, int offcy)
 {
     if (!c->skip_valid) {
-        if (!c->d_cells) HIP_TRY(hipMalloc(&c->d_cells, cells(c) * sizeof(uint4)));
+        if (!c->d_cells) { HIP_TRY(hipMalloc(&c->d_cells, cells(c) * 2 * sizeof(uint4))); c->d_pyr = c->d_cells + 1; }
         if (!c->d_tops) HIP_TRY(hipMalloc(&c->d_tops, 2 * (size_t)(c->n / 4) * (c->n / 4) * sizeof(uint16_t)));
-        if (!c->d_pyr) HIP_TRY(hipMalloc(&c->d_pyr, cells(c) * sizeof(uint4)));
         if (!c->d_build) HIP_TRY(hipMalloc(&c->d_build, 6 * cells(c)));
         const int nc = (int)c->n / 4;
         if (c->index_built && c->dirty_box) {
@@ -544,7 +543,7 @@ int vrt_destroy(vrt_ctx *c)
         if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]);
         if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]);
     }
-    void *bufs[] = {c->d_block, c->d_dist, c->d_cells, c->d_tops, c->d_pyr, c->d_build, c->own.tables, c->d_flag, c->own.sched, c->d_stage};
+    void *bufs[] = {c->d_block, c->d_dist, c->d_cells, c->d_tops, c->d_build, c->own.tables, c->d_flag, c->own.sched, c->d_stage};
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -790,9 +789,19 @@ int vrt_download_index(vrt_ctx *c, void *cells_out, void *pyr_out, uint32_t memo
     HIP_TRY(hipSetDevice(c->device));
     { int rc = ensure_skip_structure(c, -1); if (rc != VRT_OK) return rc; }
     if (pyr_out && c->pyr_offcy < 0) return fail(VRT_E_UNSUPPORTED, "the column-top pyramid is levelled by the first trace after a world change");
-    const hipMemcpyKind kind = memory == VRT_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
-    if (cells_out) HIP_TRY(hipMemcpyAsync(cells_out, c->d_cells, cells(c) * sizeof(uint4), kind, c->stream));
-    if (pyr_out) HIP_TRY(hipMemcpyAsync(pyr_out, c->d_pyr, cells(c) * sizeof(uint4), kind, c->stream));
+    // 16 of every 32 bytes each: gathered by a kernel, into the caller's device memory or into a staging buffer
+    void *stage = nullptr;
+    if (memory == VRT_MEM_HOST) HIP_TRY(hipMalloc(&stage, cells(c) * sizeof(uint4)));
+    const uint4 *src[2] = {c->d_cells, c->d_pyr};
+    void *dst[2] = {cells_out, pyr_out};
+    for (int i = 0; i < 2; ++i) {
+        if (!dst[i]) continue;
+        hipError_t e = vrt::launch_copy_every_other(src[i], static_cast<uint4 *>(stage ? stage : dst[i]), cells(c), c->stream);
+        if (e == hipSuccess && stage) e = hipMemcpyAsync(dst[i], stage, cells(c) * sizeof(uint4), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && stage) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { if (stage) (void)hipFree(stage); HIP_TRY(e); }
+    }
+    if (stage) HIP_TRY(hipFree(stage));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return VRT_OK;
 }

@@ -56,7 +56,8 @@ struct TraceParams {
     // world
     const void     *block;  // n^3 texels (u8 or u16), linear x fastest
     const uint16_t *dist;   // n^3 texels or nullptr (all zero)
-    // skip structure: one 16-byte record per cell of 4^3 voxels (torus space, linear order)
+    // skip structure: 32 bytes per cell of 4^3 voxels (torus space, linear order): the 16-byte record of cell i at
+    // cells[2 * i], its column-top pyramid words behind it at pyr[2 * i], pyr = cells + 1
     //   .x,.y  64-bit occupancy mask, bit = (z&3)*16 + (y&3)*4 + (x&3); zero for an empty cell
     //   .z,.w  eight octant distances, byte o = sx | sy<<1 | sz<<2 (bit set = positive direction):
     //          side of the largest empty cube of cells that starts at the cell and extends into
@@ -101,17 +102,18 @@ hipError_t launch_terrain(void *block, int voxel_bytes, int n, int x0, int y0, i
                           int ex, int ey, int ez, hipStream_t s);
 // `count` chunks of 32^3 voxels at chunk positions xyz[3 * i ..] (host memory), 64 chunks per launch
 hipError_t launch_terrain_chunks(void *block, int voxel_bytes, int n, const int32_t *xyz, uint32_t count, hipStream_t s);
-// cells = nc^3 records; planes = 6 * nc^3 bytes: the x and y planes of the separable octant distance transform,
+// cells = nc^3 x 32 bytes (record, pyramid words); planes = 6 * nc^3 bytes: the x and y planes of the separable octant distance transform,
 // which must keep their contents between a build and the updates that follow it
 hipError_t launch_build_cells(const void *block, int voxel_bytes, int n, uint4 *cells, uint8_t *planes, hipStream_t s);
 // The same for the cells whose voxels changed, a box of the torus (origin in [0, nc), extent 1..nc per axis), and
 // for every cell around it whose distances depend on them.
 hipError_t launch_update_cells(const void *block, int voxel_bytes, int n, uint4 *cells, uint8_t *planes, const int origin[3],
                                const int extent[3], hipStream_t s);
-// tops: scratch of at least 2 * nc * nc uint16_t; offcy = rem_euclid(lower_y, n) / 4; pyr = nc^3 records
+// tops: scratch of at least 2 * nc * nc uint16_t; offcy = rem_euclid(lower_y, n) / 4; pyr = cells + 1 (cell i's words at pyr[2 * i])
 hipError_t launch_build_voxel_pyramid(const uint4 *cells, int nc, int offcy, uint16_t *tops, uint4 *pyr, hipStream_t s);
 hipError_t launch_frame_tables(float *ncx, float *ncy, float *sin2, uint32_t w, uint32_t h, float ncy_off,
                                const int32_t sin_base[3], uint32_t sin_len, hipStream_t s);
+hipError_t launch_copy_every_other(const uint4 *src, uint4 *dst, size_t count, hipStream_t s);  // dst[i] = src[2 * i]
 hipError_t launch_any_nonzero_u16(const uint16_t *p, size_t count, uint32_t *flag, hipStream_t s);
 
 // Gathered strip buffers (parts x part_stride_rows packed rows of row_bytes each) -> frame of h rows.

@@ -264,7 +264,7 @@ VRT_DEV void traverse_skip(const TraceParams &P, float rox, float roy, float roz
         }
         const int cell = ((qz >> 2) * nc + (qy >> 2)) * nc + (qx >> 2);
         if (cell != cur_cell) {
-            const uint4 r = P.cells[cell];
+            const uint4 r = P.cells[2 * (size_t)cell];
             cur_cell = cell;
             cur_mask = (uint64_t)r.x | ((uint64_t)r.y << 32);
             d        = (int)(((dhigh ? r.w : r.z) >> dshift) & 0xffu);
@@ -401,6 +401,11 @@ struct CellRay {
     unsigned work, iters;
     uint64_t cur_mask;
     bool     live, hit;
+#ifdef VRT_DIAG_SEC_UTIL
+    // diagnostic build: lanes x trips in phase A, in the first and second unit step of phase B, and trips in which
+    // the wavefront ran phase A / phase B at all (wave uniform, counted by every lane)
+    unsigned dA = 0, dB1 = 0, dB2 = 0, dAx = 0, dBx = 0;
+#endif
 
     VRT_DEV void locate(const TraceParams &P)
     {
@@ -414,8 +419,9 @@ struct CellRay {
         // (shifts for a power of two: the 64-bit multiply-adds of the general form run at quarter rate)
         const unsigned cell = POW2 ? (unsigned)(((((qz >> 2) << P.nc_log2) | (qy >> 2)) << P.nc_log2) | (qx >> 2))
                                    : (unsigned)(((qz >> 2) * nc + (qy >> 2)) * nc + (qx >> 2));
-        const uint4 r = P.cells[cell];
-        const uint2 pw = reinterpret_cast<const uint2 *>(P.pyr)[2u * cell + (unsigned)(smy & 1)];  // rising: .x,.y
+        const uint4 *rec = P.cells + 2u * cell;  // 32 bytes per cell: the record, then the pyramid words (2 * cell < 2^32)
+        const uint4 r = rec[0];
+        const uint2 pw = reinterpret_cast<const uint2 *>(rec + 1)[smy & 1];  // rising: .x,.y
         cur_mask = (uint64_t)r.x | ((uint64_t)r.y << 32);
         d        = (int)((((dshift & 32) ? r.w : r.z) >> (dshift & 31)) & 0xffu);
         bit      = ((qz & 3) << 4) | ((qy & 3) << 2) | (qx & 3);  // off is a multiple of 4
@@ -476,6 +482,12 @@ struct CellRay {
 
     // One trip for the lanes with a live ray.  On entry the current voxel has been tested (or is the
     // start voxel) and lies inside the loaded area.
+    // FOLD > 0: when fewer than FOLD of the lanes that make this trip have no box to cross (and some lane has one),
+    // those lanes take their unit step inside phase A, as the crossing of a box of one voxel -- the same arithmetic,
+    // for no instruction more than the wavefront issues anyway -- and phase B is not run in this trip, neither for
+    // them nor for the lanes that phase A leaves without a box.  Among rays that have little to do with each other
+    // a handful of lanes per trip need a unit step, and phase B for them alone costs the wavefront half a phase A.
+    template <int FOLD = 0>
     VRT_DEV void trip(const TraceParams &P)
     {
         const int n = P.n;
@@ -485,12 +497,23 @@ struct CellRay {
         iters += 1u;
 #endif
         unsigned e = entry();
-        if (d != 0 || e != 0) {
+#ifdef VRT_DIAG_SEC_UTIL
+        dA += (d != 0 || e != 0) ? 1u : 0u;
+#endif
+        const bool boxed = d != 0 || e != 0;
+        bool fold = false;  // wave uniform
+        if (FOLD > 0) {
+            const unsigned walkers = (unsigned)__popcll(__ballot(boxed ? 0 : 1));
+            fold = walkers != 0 && walkers < (unsigned)FOLD && __any(boxed ? 1 : 0);
+        }
+        if (boxed || fold) {
             // ---- phase A: cross an empty box that holds the current voxel: the column-top block of the
             // voxel's level (also inside a non-empty cell, above its solid voxels) or the octant cube
             int fwx, fwy, fwz;  // last anchor of the box on each axis
             const int lvl = (int)(e >> 12) - 1;
-            if (e != 0 && (2 << lvl) > d) {  // (measured: better than (1 << lvl) > d and (4 << lvl) > d)
+            if (FOLD > 0 && !boxed) {
+                fwx = wx; fwy = wy; fwz = wz;  // the voxel itself
+            } else if (e != 0 && (2 << lvl) > d) {  // (measured: better than (1 << lvl) > d and (4 << lvl) > d)
                 const int m4 = (4 << lvl) - 1;
                 // texel of the current anchor up to a multiple of n, which is a multiple of the block width
                 // (qx, qz date from the last cell lookup and may lie some unit steps back)
@@ -540,13 +563,19 @@ struct CellRay {
             else if (wk > hk) live = false;
             e = entry();
         }
-        if (live && d == 0 && e == 0) {
+#ifdef VRT_DIAG_SEC_UTIL
+        dB1 += (!fold && live && d == 0 && e == 0) ? 1u : 0u;
+#endif
+        if (!fold && live && d == 0 && e == 0) {
             // ---- phase B: a few unit steps through the non-empty cell(s)
             // change of the mask bit index (z*16 + y*4 + x of the unmirrored voxel) per unit step
             const int dbx = 1 | smx, dby = 4 ^ (smy & ~7), dbz = 16 ^ (smz & ~31);  // +-1, +-4, +-16
             for (int i = 0; i < 2; ++i) {
 #ifdef VRT_DIAG_ITERS
                 iters += 0x10000u;
+#endif
+#ifdef VRT_DIAG_SEC_UTIL
+                dB2 += i;
 #endif
                 const float tx = ((float)(wx + lnx + 1) - rnx) * inx;
                 const float ty = ((float)(wy + lny + 1) - rny) * iny;
@@ -598,6 +627,11 @@ VRT_DEV bool ray_is_regular(float rdx, float rdy, float rdz)
     return ((rdx != 0.0f) & (rdy != 0.0f) & (rdz != 0.0f) & (ix < big) & (iy < big) & (iz < big)) != 0;
 }
 
+#ifndef VRT_PRIMARY_FOLD
+#define VRT_PRIMARY_FOLD 0
+#endif
+constexpr int PRIMARY_FOLD = VRT_PRIMARY_FOLD;  // CellRay::trip<FOLD> of rays traced one per lane to the end
+
 // a ray for which ray_is_regular holds
 template <typename T, bool POW2>
 VRT_DEV void traverse_cells_regular(const TraceParams &P, float rox, float roy, float roz, float rdx, float rdy,
@@ -606,7 +640,7 @@ VRT_DEV void traverse_cells_regular(const TraceParams &P, float rox, float roy, 
     CellRay<T, POW2> ray;
     ray.template begin<false>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, f2i_small(floorf(rox)),
                               f2i_small(floorf(roy)), f2i_small(floorf(roz)), 0u);
-    while (ray.live) ray.trip(P);
+    while (ray.live) ray.template trip<PRIMARY_FOLD>(P);
     ray.finish(P, rox, roy, roz, lox, loy, loz, H);
 }
 
@@ -1133,6 +1167,10 @@ constexpr unsigned SEC_BINS = 17;  // 16 elevation classes of ambient-occlusion 
 #ifndef VRT_SEC_WAVES
 #define VRT_SEC_WAVES 8
 #endif
+#ifndef VRT_SEC_FOLD
+#define VRT_SEC_FOLD 64
+#endif
+constexpr int SEC_FOLD = VRT_SEC_FOLD;  // CellRay::trip<FOLD> of the binned kernel's rays
 constexpr unsigned SEC_REFILL = VRT_SEC_REFILL;  // free lanes at which a wavefront draws new rays (1..64; 64: whole bundles)
 
 template <typename T, int FORM>
@@ -1236,6 +1274,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VRT_SEC_WAV
         ray.idle();
         unsigned mine = 0;      // pixel | ray index << 8 of the ray this lane holds
         unsigned trips = 0;     // wave uniform: trips of the traversal loop this wavefront ran
+#ifdef VRT_DIAG_SEC_UTIL
+        unsigned dRefills = 0, dRefillLanes = 0, dLive = 0, dBegun = 0;
+#endif
         bool     drained = false;  // wave uniform: the list has no ray left for this wavefront
         for (;;) {
             const unsigned long long free_lanes = __ballot(ray.live ? 0 : 1);
@@ -1246,6 +1287,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VRT_SEC_WAV
                 first = (unsigned)__builtin_amdgcn_readfirstlane((int)first);
                 drained = first + nfree >= total;
                 const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(free_lanes >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)free_lanes, 0u));
+#ifdef VRT_DIAG_SEC_UTIL
+                dRefills += 1u; dRefillLanes += nfree; dBegun += (!ray.live && first + rank < total) ? 1u : 0u;
+#endif
                 if (!ray.live && first + rank < total) {
                     const unsigned at = first + rank;
                     mine = s_ray[at];
@@ -1275,8 +1319,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VRT_SEC_WAV
                 continue;  // every lane is free: the next round refills them
             }
             trips += 1u;
+#ifdef VRT_DIAG_SEC_UTIL
+            dLive += ray.live ? 1u : 0u;
+            ray.dAx += __any((ray.live && (ray.d != 0 || ray.entry() != 0)) ? 1 : 0) ? 1u : 0u;
+#endif
             if (ray.live) {
-                ray.trip(P);
+                ray.template trip<SEC_FOLD>(P);
                 if (!ray.live) {  // ended in this trip: its result goes to its pixel
                     const unsigned pix = mine & 255u;
                     atomicAdd(&s_steps[pix], ray.steps_done());
@@ -1285,8 +1333,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VRT_SEC_WAV
             }
         }
         work += trips;
+#ifdef VRT_DIAG_SEC_UTIL
+        // counters summed over the launch into sec_steps[0..9] (the plane itself is not written in this build)
+        if (sec_steps) {
+            auto wsum = [](unsigned v) { for (int o = 32; o > 0; o >>= 1) v += (unsigned)__shfl_xor((int)v, o); return v; };
+            const unsigned sA = wsum(ray.dA), sB1 = wsum(ray.dB1), sB2 = wsum(ray.dB2), sLive = wsum(dLive), sBegun = wsum(dBegun);
+            if (lane == 0) {
+                atomicAdd(&sec_steps[0], trips); atomicAdd(&sec_steps[1], sLive); atomicAdd(&sec_steps[2], sA);
+                atomicAdd(&sec_steps[3], sB1); atomicAdd(&sec_steps[4], sB2); atomicAdd(&sec_steps[5], ray.dAx);
+                atomicAdd(&sec_steps[6], dRefills); atomicAdd(&sec_steps[7], dRefillLanes); atomicAdd(&sec_steps[8], sBegun);
+                atomicAdd(&sec_steps[9], 1u);
+            }
+        }
+#endif
     }
     __syncthreads();
+#ifdef VRT_DIAG_SEC_UTIL
+    sec_steps = nullptr;
+#endif
 
     // ---- phase 3: every lane stores its own pixel (coordinates worked out again rather than kept across the phases)
     if (pixel_of_thread(P, by, opaque(tid), col, q, row)) {

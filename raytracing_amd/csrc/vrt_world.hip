@@ -179,6 +179,10 @@ hipError_t launch_terrain(void *block, int voxel_bytes, int n, int x0, int y0, i
 // ---------------------------------------------------------------------------
 // cell records: cell (cx,cy,cz) covers texels [4c, 4c+4)^3
 // ---------------------------------------------------------------------------
+// A cell's record and its column-top pyramid words lie side by side, 32 bytes per cell: `cells` points at the
+// record of cell 0 and cell i's is cells[2 * i]; the pyramid kernel writes `out`[2 * i] with out = cells + 1.  A ray
+// that lands in a cell reads both, and among rays that have little to do with each other that is one miss in the
+// L2 per cell instead of two.
 // Every builder below works on a box of cells of the torus: origin o (each coordinate in [0, nc)) and extent e
 // (1..nc per axis); the cell of a thread is (o + local) mod nc.  The whole torus is the box (0, nc); after a few
 // chunks have been regenerated only the cells whose records can have changed are visited (launch_update_cells).
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(256) void k_cell_masks(const T *block, int n, int n
             m |= (uint64_t)bits << (z * 16 + y * 4);
         }
     }
-    uint2 *dst = reinterpret_cast<uint2 *>(cells + ((size_t)cz * nc + cy) * nc + cx);
+    uint2 *dst = reinterpret_cast<uint2 *>(cells + 2 * (((size_t)cz * nc + cy) * nc + cx));
     *dst = make_uint2((unsigned)m, (unsigned)(m >> 32));
 }
 
@@ -259,7 +263,7 @@ __global__ __launch_bounds__(256) void k_df_x(const uint4 *cells, int nc, CellBo
     if (!box_cell(box, nc, cx, cy, cz)) return;
     const size_t ncells = (size_t)nc * nc * nc, line = ((size_t)cz * nc + cy) * nc;
     auto value = [&](int q) -> int {
-        const uint2 m = *reinterpret_cast<const uint2 *>(cells + line + q);
+        const uint2 m = *reinterpret_cast<const uint2 *>(cells + 2 * (line + q));
         return (m.x | m.y) != 0 ? 0 : DF_CAP;
     };
     const int self = value(cx);
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(256) void k_df_z_pack(const uint8_t *ty, int nc, Ce
         lo |= (unsigned)df_scan(value, self, cz, nc, -1) << (8 * sxy);
         hi |= (unsigned)df_scan(value, self, cz, nc, 1) << (8 * sxy);
     }
-    uint2 *dst = reinterpret_cast<uint2 *>(cells + (size_t)cz * plane + base) + 1;
+    uint2 *dst = reinterpret_cast<uint2 *>(cells + 2 * ((size_t)cz * plane + base)) + 1;
     *dst = make_uint2(lo, hi);
 }
 
@@ -373,7 +377,7 @@ __global__ __launch_bounds__(256) void k_column_vtops(const uint4 *cells, int nc
     for (int wl = nc - 1; wl >= 0; --wl) {
         int tcy = wl + offcy;
         tcy -= tcy >= nc ? nc : 0;
-        const uint4 rec = cells[((size_t)tcz * nc + tcy) * nc + tcx];
+        const uint4 rec = cells[2 * (((size_t)tcz * nc + tcy) * nc + tcx)];
         if ((rec.z & 0xffu) != 0) continue;  // empty cell
         const uint64_t m = (uint64_t)rec.x | ((uint64_t)rec.y << 32);
         int y = 3;
@@ -412,7 +416,7 @@ __global__ __launch_bounds__(256) void k_voxel_pyramid(int nc, int offcy, Pyrami
         }
         up[j] = widest; down[j] = best;
     }
-    out[((size_t)tcz * nc + tcy) * nc + tcx] =
+    out[2 * (((size_t)tcz * nc + tcy) * nc + tcx)] =
         make_uint4(up[0] | (up[1] << 16), up[2] | (up[3] << 16), down[0] | (down[1] << 16), down[2] | (down[3] << 16));
 }
 
@@ -432,6 +436,20 @@ hipError_t launch_build_voxel_pyramid(const uint4 *cells, int nc, int offcy, uin
         pyr.tops[L] = level; pyr.size[L] = size; pyr.levels = L;
     }
     k_voxel_pyramid<<<dim3((nc + 63) / 64, (nc + 3) / 4, nc), blockdim, 0, s>>>(nc, offcy, pyr, out);
+    return hipGetLastError();
+}
+
+// dst[i] = src[2 * i]: the records, or the pyramid words, out of the 32-byte cells
+__global__ __launch_bounds__(256) void k_copy_every_other(const uint4 *src, uint4 *dst, size_t count)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < count) dst[i] = src[2 * i];
+}
+
+hipError_t launch_copy_every_other(const uint4 *src, uint4 *dst, size_t count, hipStream_t s)
+{
+    if (count == 0) return hipSuccess;
+    k_copy_every_other<<<(unsigned)((count + 255) / 256), 256, 0, s>>>(src, dst, count);
     return hipGetLastError();
 }
 

@@ -1,0 +1,9 @@
+#!/bin/bash
+# A/B of several builds of the library on BASELINE config 5 (tools/ab_secondary.py per build, which also checks that the
+# binned kernel's planes equal the per-pixel kernel's).  usage: bash tools/ab_sec_libs.sh rounds lib1.so lib2.so ...
+set -u
+rounds=$1; shift
+for lib in "$@"; do
+  echo "$lib"
+  VRT_LIB=$PWD/$lib timeout -k 10 200 python tools/ab_secondary.py "$rounds" 2>/dev/null || exit 1
+done

@@ -389,6 +389,9 @@ VRT_DEV void traverse_skip(const TraceParams &P, float rox, float roy, float roz
 // whose ray is live, finish() turns the end state into the reference's outputs.  traverse_cells
 // below runs one ray per lane to the end; the stream kernel keeps lanes busy by starting a new ray
 // in a lane whose ray has ended.
+#ifndef VRT_MARGIN
+#define VRT_MARGIN 0x1.0p-20f
+#endif
 template <typename T, bool POW2>
 struct CellRay {
     // per ray constants (mirrored frame)
@@ -404,7 +407,7 @@ struct CellRay {
 #ifdef VRT_DIAG_SEC_UTIL
     // diagnostic build: lanes x trips in phase A, in the first and second unit step of phase B, and trips in which
     // the wavefront ran phase A / phase B at all (wave uniform, counted by every lane)
-    unsigned dA = 0, dB1 = 0, dB2 = 0, dAx = 0, dBx = 0;
+    unsigned dA = 0, dB1 = 0, dB2 = 0, dAx = 0, dBx = 0, dNear = 0, dNearX = 0;  // lanes near a plane; trips that ran the settling code
 #endif
 
     VRT_DEV void locate(const TraceParams &P)
@@ -459,10 +462,10 @@ struct CellRay {
         lnx = px ? lox : -lox; lny = py ? loy : -loy; lnz = pz ? loz : -loz;
         const int oct = (px ? 1 : 0) | (py ? 2 : 0) | (pz ? 4 : 0);
         dshift = 8 * (oct & 3) + (oct >= 4 ? 32 : 0);
-        // margin of the exit-point test, as 0.5 - 2^-20 * (|pos| + |origin| + 1) = thr0 - 2^-20 * |pos|
-        thr0x = zx ? never : 0.5f - 0x1.0p-20f * (fabsf(rnx) + 1.0f);
-        thr0y = zy ? never : 0.5f - 0x1.0p-20f * (fabsf(rny) + 1.0f);
-        thr0z = zz ? never : 0.5f - 0x1.0p-20f * (fabsf(rnz) + 1.0f);
+        // margin of the exit-point test, as 0.5 - VRT_MARGIN * (|pos| + |origin| + 1) = thr0 - VRT_MARGIN * |pos|
+        thr0x = zx ? never : 0.5f - VRT_MARGIN * (fabsf(rnx) + 1.0f);
+        thr0y = zy ? never : 0.5f - VRT_MARGIN * (fabsf(rny) + 1.0f);
+        thr0z = zz ? never : 0.5f - VRT_MARGIN * (fabsf(rnz) + 1.0f);
         wx = wsub(ax, lox) ^ smx; wy = wsub(ay, loy) ^ smy; wz = wsub(az, loz) ^ smz;
         // every step moves one axis by +1 in the mirrored frame: the step count is the distance from here
         w0 = wx + wy + wz - (int)steps;
@@ -538,9 +541,13 @@ struct CellRay {
             const float psx = rnx + dnx * tk, psy = rny + dny * tk, psz = rnz + dnz * tk;
             const float flx = floorf(psx), fly = floorf(psy), flz = floorf(psz);
             int vx = f2i_small(flx) - lnx, vy = f2i_small(fly) - lny, vz = f2i_small(flz) - lnz;
-            const bool nearx = fabsf((psx - flx) - 0.5f) >= __builtin_fmaf(fabsf(psx), -0x1.0p-20f, thr0x);
-            const bool neary = fabsf((psy - fly) - 0.5f) >= __builtin_fmaf(fabsf(psy), -0x1.0p-20f, thr0y);
-            const bool nearz = fabsf((psz - flz) - 0.5f) >= __builtin_fmaf(fabsf(psz), -0x1.0p-20f, thr0z);
+            const bool nearx = fabsf((psx - flx) - 0.5f) >= __builtin_fmaf(fabsf(psx), -VRT_MARGIN, thr0x);
+            const bool neary = fabsf((psy - fly) - 0.5f) >= __builtin_fmaf(fabsf(psy), -VRT_MARGIN, thr0y);
+            const bool nearz = fabsf((psz - flz) - 0.5f) >= __builtin_fmaf(fabsf(psz), -VRT_MARGIN, thr0z);
+#ifdef VRT_DIAG_SEC_UTIL
+            dNear += (nearx || neary || nearz) ? 1u : 0u;
+            dNearX += __any((nearx || neary || nearz) ? 1 : 0) ? 1u : 0u;
+#endif
             if (__any((nearx || neary || nearz) ? 1 : 0)) {
                 const float i0x = rintf(psx), i0y = rintf(psy), i0z = rintf(psz);
                 const float ttx = (i0x - rnx) * inx, tty = (i0y - rny) * iny, ttz = (i0z - rnz) * inz;
@@ -1005,17 +1012,10 @@ VRT_DEV unsigned pcg_hash(unsigned v)
     return (word >> 22u) ^ word;
 }
 
-VRT_DEV void secondary_dir(unsigned pixel_index, unsigned index, int face, float &dx, float &dy, float &dz)
+// Ambient-occlusion direction from the ray's hash h1 (the second hash of the pair follows from it), about `face`.
+VRT_DEV void ao_dir_from_hash(unsigned h1, int face, float &dx, float &dy, float &dz)
 {
-    if (index == 0) {
-        const float lx = 0.4f, ly = 0.8f, lz = 0.45f;
-        const float len = sqrtf((lx * lx + ly * ly) + lz * lz);
-        dx = lx / len; dy = ly / len; dz = lz / len;
-        return;
-    }
-    unsigned hsh = pcg_hash(0x5EEDu ^ pixel_index);
-    for (unsigned j = 1; j < index; ++j) { hsh = pcg_hash(hsh); hsh = pcg_hash(hsh); }
-    const unsigned h1 = hsh, h2 = pcg_hash(hsh);
+    const unsigned h2 = pcg_hash(h1);
     const float u1 = (float)(h1 >> 8) * 0x1.0p-24f, u2 = (float)(h2 >> 8) * 0x1.0p-24f;
     const float r = sqrtf(u1), phi = 6.2831855f * u2;
     const float tx = r * canon_sin(phi + 1.5707964f);
@@ -1027,6 +1027,19 @@ VRT_DEV void secondary_dir(unsigned pixel_index, unsigned index, int face, float
     dx = k == 0 ? nz : (k == 2 ? tx : ty);
     dy = k == 1 ? nz : (k == 0 ? tx : ty);
     dz = k == 2 ? nz : (k == 1 ? tx : ty);
+}
+
+VRT_DEV void secondary_dir(unsigned pixel_index, unsigned index, int face, float &dx, float &dy, float &dz)
+{
+    if (index == 0) {
+        const float lx = 0.4f, ly = 0.8f, lz = 0.45f;
+        const float len = sqrtf((lx * lx + ly * ly) + lz * lz);
+        dx = lx / len; dy = ly / len; dz = lz / len;
+        return;
+    }
+    unsigned hsh = pcg_hash(0x5EEDu ^ pixel_index);
+    for (unsigned j = 1; j < index; ++j) { hsh = pcg_hash(hsh); hsh = pcg_hash(hsh); }
+    ao_dir_from_hash(hsh, face, dx, dy, dz);
 }
 
 // The secondary-ray kernel keeps its seldom used code out of line for the same reason as k_trace_skip
@@ -1194,6 +1207,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VRT_SEC_WAV
     // ---- phase 1: the primary ray of this lane's pixel
     unsigned col, q, row, work = 0;
     unsigned bins = 0;  // five 5-bit bin numbers of this pixel's rays, ray 0 lowest; only meaningful after a hit
+    unsigned ao_hash[4] = {0, 0, 0, 0};  // first hash of each ambient-occlusion ray's pair
     bool     hit = false;
     const bool inside = pixel_of_thread(P, by, tid, col, q, row);
     if (inside) {
@@ -1227,6 +1241,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VRT_SEC_WAV
             unsigned hsh = pcg_hash(0x5EEDu ^ (row * P.w + col));
             bins = SEC_BINS - 1;  // the shadow ray
             for (unsigned j = 0; j < 4; ++j) {
+                ao_hash[j] = hsh;
                 bins |= (15u - (hsh >> 28)) << (5u * (j + 1u));
                 hsh = pcg_hash(hsh); hsh = pcg_hash(hsh);
             }
@@ -1240,24 +1255,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VRT_SEC_WAV
         s_total = run;
     }
     __syncthreads();
-    if (hit)
-        for (unsigned j = 0; j < 5; ++j) {
-            const unsigned at = atomicAdd(&s_base[(bins >> (5u * j)) & 31u], 1u);
-            s_ray[at] = (unsigned short)(tid | (j << 8));
+    // every hit pixel's lane puts its five rays into the list, and the directions of its four ambient-occlusion rays
+    // beside them (the list's tail of shadow rays shares one direction and has none stored)
+    if (hit) {
+        const int face = (int)s_face[tid];
+        s_ray[atomicAdd(&s_base[SEC_BINS - 1], 1u)] = (unsigned short)tid;
+        for (unsigned j = 0; j < 4; ++j) {
+            const unsigned at = atomicAdd(&s_base[(bins >> (5u * (j + 1u))) & 31u], 1u);
+            s_ray[at] = (unsigned short)(tid | ((j + 1u) << 8));
+            float dx, dy, dz;
+            ao_dir_from_hash(ao_hash[j], face, dx, dy, dz);
+            s_dir[0][at] = dx; s_dir[1][at] = dy; s_dir[2][at] = dz;
         }
-    __syncthreads();
-    // the directions of the ambient-occlusion rays (all of the list but its tail of shadow rays), worked out by all
-    // 256 lanes side by side rather than by whichever lanes are free when a ray is drawn
-    const unsigned total = s_total, n_ao = total - s_count[SEC_BINS - 1];
-    for (unsigned at = tid; at < n_ao; at += 256u) {
-        const unsigned rec = s_ray[at], pix = rec & 255u;
-        unsigned pcol, pq, prow;
-        pixel_of_thread(P, by, pix, pcol, pq, prow);
-        float dx, dy, dz;
-        secondary_dir(prow * P.w + pcol, rec >> 8, (int)s_face[pix], dx, dy, dz);
-        s_dir[0][at] = dx; s_dir[1][at] = dy; s_dir[2][at] = dz;
     }
     __syncthreads();
+    const unsigned total = s_total, n_ao = total - s_count[SEC_BINS - 1];
 
     // ---- phase 2: every wavefront traces rays of the list until it is empty.  A lane whose ray has ended
     // takes the next ray of the list as soon as SEC_REFILL lanes of its wavefront are free (one LDS ticket for
@@ -1343,6 +1355,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VRT_SEC_WAV
                 atomicAdd(&sec_steps[3], sB1); atomicAdd(&sec_steps[4], sB2); atomicAdd(&sec_steps[5], ray.dAx);
                 atomicAdd(&sec_steps[6], dRefills); atomicAdd(&sec_steps[7], dRefillLanes); atomicAdd(&sec_steps[8], sBegun);
                 atomicAdd(&sec_steps[9], 1u);
+                atomicAdd(&sec_steps[10], wsum(ray.dNear)); atomicAdd(&sec_steps[11], wsum(ray.dNearX) / 64u);
             }
         }
 #endif

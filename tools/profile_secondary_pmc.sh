@@ -3,7 +3,7 @@
 #   bash tools/profile_secondary_pmc.sh   -> gpurun_out/prof_sec/<variant>/pmc_<pass>/ and a summary per variant
 set -u
 export TMPDIR=/tmp
-for variant in pixel binned; do
+for variant in ${VARIANTS:-pixel binned}; do
   OUT=gpurun_out/prof_sec/$variant
   mkdir -p "$OUT"
   run_pass() {

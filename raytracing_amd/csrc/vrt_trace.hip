@@ -1284,7 +1284,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VRT_SEC_WAV
         secondary_dir(0u, 0u, 0, lightx, lighty, lightz);  // the shadow rays' one direction
         CellRay<T, FORM == FORM_POW2> ray;
         ray.idle();
-        unsigned mine = 0;      // pixel | ray index << 8 of the ray this lane holds
+        constexpr unsigned NO_RAY = 0xffffffffu;
+        unsigned mine = NO_RAY;  // pixel | ray index << 8 of the ray this lane holds, live or ended and not yet delivered
+        // the result of an ended ray goes to its pixel when the lane next draws (or at the end), together with the
+        // other free lanes' results, rather than in the trip it ended in with the few lanes that ended with it
+        auto deliver = [&]() {
+            if (mine != NO_RAY) {
+                const unsigned pix = mine & 255u;
+                atomicAdd(&s_steps[pix], ray.steps_done());
+                if (ray.hit) atomicAdd(&s_hits[pix], (mine >> 8) == 0 ? 1u : 256u);
+                mine = NO_RAY;
+            }
+        };
         unsigned trips = 0;     // wave uniform: trips of the traversal loop this wavefront ran
 #ifdef VRT_DIAG_SEC_UTIL
         unsigned dRefills = 0, dRefillLanes = 0, dLive = 0, dBegun = 0;
@@ -1302,10 +1313,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VRT_SEC_WAV
 #ifdef VRT_DIAG_SEC_UTIL
                 dRefills += 1u; dRefillLanes += nfree; dBegun += (!ray.live && first + rank < total) ? 1u : 0u;
 #endif
+                if (!ray.live) deliver();
                 if (!ray.live && first + rank < total) {
                     const unsigned at = first + rank;
-                    mine = s_ray[at];
-                    const unsigned pix = mine & 255u, j = mine >> 8;
+                    const unsigned rec = s_ray[at];
+                    const unsigned pix = rec & 255u, j = rec >> 8;
                     const unsigned dat = min(at, 4u * 256u - 1u);
                     const float sdx = at < n_ao ? s_dir[0][dat] : lightx, sdy = at < n_ao ? s_dir[1][dat] : lighty,
                                 sdz = at < n_ao ? s_dir[2][dat] : lightz;
@@ -1318,7 +1330,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VRT_SEC_WAV
                     } else if (ray_is_regular(sdx, sdy, sdz)) {
                         ray.template begin<false>(P, sox, soy, soz, sdx, sdy, sdz, lox, loy, loz, f2i_small(floorf(sox)),
                                                   f2i_small(floorf(soy)), f2i_small(floorf(soz)), 0u);
-                        if (!ray.live) atomicAdd(&s_steps[pix], ray.steps_done());  // starts outside the loaded area
+                        mine = rec;  // (a ray that starts outside the loaded area is not live and is delivered as it is)
                     } else {
                         const unsigned r = degenerate_ray<T, FORM>(params, sox, soy, soz, sdx, sdy, sdz);
                         atomicAdd(&s_steps[pix], r & 0x7fffffffu);
@@ -1335,27 +1347,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VRT_SEC_WAV
             dLive += ray.live ? 1u : 0u;
             ray.dAx += __any((ray.live && (ray.d != 0 || ray.entry() != 0)) ? 1 : 0) ? 1u : 0u;
 #endif
-            if (ray.live) {
-                ray.template trip<SEC_FOLD>(P);
-                if (!ray.live) {  // ended in this trip: its result goes to its pixel
-                    const unsigned pix = mine & 255u;
-                    atomicAdd(&s_steps[pix], ray.steps_done());
-                    if (ray.hit) atomicAdd(&s_hits[pix], (mine >> 8) == 0 ? 1u : 256u);
-                }
-            }
+            if (ray.live) ray.template trip<SEC_FOLD>(P);
         }
+        deliver();
         work += trips;
 #ifdef VRT_DIAG_SEC_UTIL
         // counters summed over the launch into sec_steps[0..9] (the plane itself is not written in this build)
         if (sec_steps) {
             auto wsum = [](unsigned v) { for (int o = 32; o > 0; o >>= 1) v += (unsigned)__shfl_xor((int)v, o); return v; };
             const unsigned sA = wsum(ray.dA), sB1 = wsum(ray.dB1), sB2 = wsum(ray.dB2), sLive = wsum(dLive), sBegun = wsum(dBegun);
+            const unsigned sNear = wsum(ray.dNear), sNearX = wsum(ray.dNearX);
             if (lane == 0) {
                 atomicAdd(&sec_steps[0], trips); atomicAdd(&sec_steps[1], sLive); atomicAdd(&sec_steps[2], sA);
                 atomicAdd(&sec_steps[3], sB1); atomicAdd(&sec_steps[4], sB2); atomicAdd(&sec_steps[5], ray.dAx);
                 atomicAdd(&sec_steps[6], dRefills); atomicAdd(&sec_steps[7], dRefillLanes); atomicAdd(&sec_steps[8], sBegun);
                 atomicAdd(&sec_steps[9], 1u);
-                atomicAdd(&sec_steps[10], wsum(ray.dNear)); atomicAdd(&sec_steps[11], wsum(ray.dNearX) / 64u);
+                atomicAdd(&sec_steps[10], sNear); atomicAdd(&sec_steps[11], sNearX);
             }
         }
 #endif

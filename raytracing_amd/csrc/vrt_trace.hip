@@ -1165,14 +1165,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 // k_trace_secondary gives every pixel's five rays to the pixel's own lane, pass by pass: lanes whose primary
 // ray missed idle through all five passes, and the four ambient-occlusion rays a wavefront traces together
 // point anywhere in their hemispheres.  Here the workgroup (a 16 x 16 pixel tile) turns its primary hits into
-// a list of rays in LDS -- one 16-bit record per ray (pixel of the tile, ray index); origin and face once per
-// pixel; the direction is re-derived from the pixel's hash by whoever traces the ray -- sorted by direction
+// a list of rays in LDS -- one 16-bit record per ray (pixel of the tile, ray index) with the direction beside it
+// (worked out by the pixel's own lane as it places the ray); origin and face once per pixel -- sorted by direction
 // class (counting sort over LDS counters): ambient-occlusion rays by elevation above their surface in sixteen
 // classes, the shallowest (which skim the terrain and run longest) first, the shadow rays (one direction for
-// the whole frame) last.  The four wavefronts then pull 64 consecutive rays at a time from the list through an
-// LDS ticket until it is empty; no lane idles for a pixel that missed, a wavefront's rays have alike
-// elevations, and a wavefront that draws short rays takes more of them.  Results are summed per pixel with
-// LDS atomics (integer sums: the order of arrival does not matter) and stored by the pixel's own lane.
+// the whole frame, none stored) last.  The four wavefronts then draw rays from the list through an LDS ticket
+// until it is empty: a wavefront draws as soon as SEC_REFILL of its lanes are free, so no lane idles for a pixel
+// that missed, a wavefront's rays have alike elevations, and a wavefront that draws short rays takes more of
+// them.  Unit steps are folded into the box phase of the traversal (CellRay::trip<SEC_FOLD>): among rays that
+// have little to do with each other a handful of lanes per trip need one, which does not pay for a phase of its
+// own.  Results are summed per pixel with LDS atomics (integer sums: the order of arrival does not matter), by
+// the lanes that are about to draw, and stored by the pixel's own lane.
+// Measured on 1920 x 1080 over the 1024^3 terrain, 5.9 M secondary rays: 32.3 Grays/s, 0.67 of the lanes active
+// per vector instruction, against 22.2 Grays/s and 0.45 for k_trace_secondary.
 constexpr unsigned SEC_BINS = 17;  // 16 elevation classes of ambient-occlusion rays + the shadow rays
 #ifndef VRT_SEC_REFILL
 #define VRT_SEC_REFILL 24

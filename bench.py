@@ -119,7 +119,10 @@ def literal_roofline(device, cam, wmin, alg_bytes, skip_frame):
     s = ms / 1e3 / n
     return {"bound": "hbm", "achieved": alg_bytes / s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": alg_bytes / s / 1e9 / HBM_PEAK_GBS, "kernel": "literal", "kernel_ms": s * 1e3, "timed_launches": int(n),
-            "algorithmic_bytes_per_launch": alg_bytes, "frame_equals_skip_kernel_frame": same}
+            "algorithmic_bytes_per_launch": alg_bytes, "frame_equals_skip_kernel_frame": same,
+            "limiter": "one dependent voxel load per iteration (about 0.65 us per iteration of a wavefront) beside 55-75 vector "
+                       "instructions per iteration from each of the SIMD's eight wavefronts: load latency and instruction "
+                       "issue bind together, HBM bandwidth does not (profiles/r02_dropped/literal_lean_loop.txt)"}
 
 
 def copy_bandwidth_gbs(nbytes=1 << 30, reps=10):

@@ -53,9 +53,11 @@ def test_oracle_secondary_on_a_flat_floor():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kernel", ["binned", "pixel"])  # rays staged and binned in LDS (the default), or on their pixel's lane
 @pytest.mark.parametrize("n,dtype", [(160, np.uint16), (256, np.uint8)])
-def test_gpu_secondary_matches_oracle(n, dtype):
+def test_gpu_secondary_matches_oracle(n, dtype, kernel, monkeypatch):
     from raytracing_amd import GraphicsCore, VOXEL_PACKED_U8, VOXEL_REF_U16U16
+    monkeypatch.setenv("VRT_SECONDARY", kernel)  # read when the context is created
     p = scenes.pose_b()
     block = O.terrain_fill(n, scenes.window_min(p.get_position(), n), dtype)
     cam = scenes.cam16(p)
@@ -74,8 +76,10 @@ def test_gpu_secondary_matches_oracle(n, dtype):
 
 
 @pytest.mark.gpu
-def test_gpu_secondary_on_random_grid_with_degenerate_rays():
+@pytest.mark.parametrize("kernel", ["binned", "pixel"])
+def test_gpu_secondary_on_random_grid_with_degenerate_rays(kernel, monkeypatch):
     from raytracing_amd import GraphicsCore, Player, VOXEL_PACKED_U8
+    monkeypatch.setenv("VRT_SECONDARY", kernel)
     rng = np.random.default_rng(9)
     n = 64
     block = ((rng.random((n, n, n)) < 0.02) * rng.integers(1, 9, (n, n, n))).astype(np.uint8)
@@ -87,3 +91,24 @@ def test_gpu_secondary_on_random_grid_with_degenerate_rays():
             got = g.trace_secondary(cam, 96, 64)
             for k in ("shadow", "ao", "sec_steps"):
                 assert np.array_equal(got[k], want[k]), (k, pos)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel", ["binned", "pixel"])
+def test_gpu_secondary_with_a_small_step_cap(kernel, monkeypatch):
+    """A step cap below 3n selects the one-step-per-trip form of the traversal, which the binned kernel runs whole
+    for each ray it draws; capped secondary rays count as misses with max_steps iterations."""
+    from raytracing_amd import GraphicsCore, Player, VOXEL_PACKED_U8
+    monkeypatch.setenv("VRT_SECONDARY", kernel)
+    rng = np.random.default_rng(21)
+    n, cap = 96, 60
+    block = ((rng.random((n, n, n)) < 0.004) * rng.integers(1, 9, (n, n, n))).astype(np.uint8)
+    block[:, :20, :] = 3  # a floor, so that most pixels hit
+    cam = scenes.cam16(Player.at((40.2, 30.7, 44.9), 0.7, -0.6))
+    want = O.trace_secondary(O.World(block, max_steps=cap), cam, 160, 96)
+    with GraphicsCore(grid_n=n, voxel_format=VOXEL_PACKED_U8, max_steps=cap) as g:
+        g.upload_world(block)
+        got = g.trace_secondary(cam, 160, 96)
+    for k in ("shadow", "ao", "sec_steps"):
+        assert np.array_equal(got[k], want[k]), k
+    assert want["sec_steps"].max() >= cap and want["shadow"].any()

@@ -999,6 +999,69 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     }
 }
 
+#ifdef VRT_PRIMARY_STREAM
+// ---------------------------------------------------------------------------
+// primary rays with lane refill (an experiment, built only with EXTRA=-DVRT_PRIMARY_STREAM=R; measured slower than
+// k_trace_skip and kept for that record)
+// ---------------------------------------------------------------------------
+// A wavefront traces R tiles of 16 x 4 pixels -- the workgroup rows blockIdx.y, blockIdx.y + gridDim.y, ... -- and a
+// lane whose ray has ended starts on its pixel of its next tile as soon as VRT_STREAM_REFILL lanes wait (ballot of the
+// waiting lanes), instead of idling until the wavefront's longest ray ends.  The ray is the resumable CellRay of the
+// binned secondary-ray kernel; an ended ray is finished (shading, stores) when its lane next draws.
+#ifndef VRT_STREAM_REFILL
+#define VRT_STREAM_REFILL 24
+#endif
+#ifndef VRT_STREAM_WAVES
+#define VRT_STREAM_WAVES 8
+#endif
+template <typename T, int FORM>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VRT_STREAM_WAVES, 8))) void k_trace_skip_stream(const TraceParams P)
+{
+    constexpr unsigned R = VRT_PRIMARY_STREAM;
+    const unsigned tid = threadIdx.x;
+    const unsigned block_rows = 4u << P.tile_log2h, total_rows = (P.rows.rows + block_rows - 1) / block_rows;
+    const float rox = P.m[12], roy = P.m[13], roz = P.m[14];
+    const int lox = P.lo[0], loy = P.lo[1], loz = P.lo[2];
+    CellRay<T, FORM == FORM_POW2> ray;
+    ray.idle();
+    unsigned j = 0;        // tiles this lane has started
+    bool holding = false;  // the lane holds a ray of tile j - 1, live or ended and not yet finished
+    for (;;) {
+        const bool waiting = !ray.live && (holding || j < R);
+        const unsigned nwait = (unsigned)__popcll(__ballot(waiting ? 1 : 0));
+        const bool none_live = !__any(ray.live ? 1 : 0);
+        if (nwait == 0 && none_live) break;
+        if (nwait >= VRT_STREAM_REFILL || none_live) {
+            if (waiting) {
+                unsigned col, q, row;
+                if (holding) {
+                    pixel_of_thread(P, blockIdx.y + (j - 1u) * gridDim.y, tid, col, q, row);
+                    RayHit H;
+                    ray.finish(P, rox, roy, roz, lox, loy, loz, H);
+                    finish_pixel(P, col, P.h - row, (size_t)q * P.w + col, H);
+                    holding = false;
+                }
+                while (j < R && !holding) {
+                    const unsigned by = blockIdx.y + j * gridDim.y;
+                    ++j;
+                    if (by >= total_rows || !pixel_of_thread(P, by, tid, col, q, row)) continue;
+                    float rdx, rdy, rdz;
+                    raygen(P, col, P.h - row, rdx, rdy, rdz);
+                    if (ray_is_regular(rdx, rdy, rdz)) {
+                        ray.template begin<false>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, f2i_small(floorf(rox)),
+                                                  f2i_small(floorf(roy)), f2i_small(floorf(roz)), 0u);
+                        holding = true;
+                    } else {
+                        degenerate_pixel<T, FORM>((const TraceParams *)__builtin_amdgcn_kernarg_segment_ptr(), col, P.h - row, q);
+                    }
+                }
+            }
+        }
+        if (ray.live) ray.template trip<PRIMARY_FOLD>(P);
+    }
+}
+#endif
+
 // ---------------------------------------------------------------------------
 // secondary rays per primary hit (no reference counterpart: the shader casts primary rays
 // only).  One shadow ray towards normalize(0.4, 0.8, 0.45) and four cosine-distributed
@@ -1445,6 +1508,19 @@ hipError_t launch_trace_skip(const TraceParams &p, int voxel_bytes, hipStream_t 
     if (p.rows.rows == 0 || p.w == 0) return hipSuccess;
     const dim3 grid = trace_grid(p), block(256);
     const int form = trace_form(p);
+#ifdef VRT_PRIMARY_STREAM
+    if (form != FORM_CAPPED) {
+        const dim3 sgrid(grid.x, (grid.y + VRT_PRIMARY_STREAM - 1) / VRT_PRIMARY_STREAM, 1);
+        if (voxel_bytes == 1) {
+            if (form == FORM_POW2) k_trace_skip_stream<uint8_t, FORM_POW2><<<sgrid, block, 0, s>>>(p);
+            else k_trace_skip_stream<uint8_t, FORM_ANY_N><<<sgrid, block, 0, s>>>(p);
+        } else {
+            if (form == FORM_POW2) k_trace_skip_stream<uint16_t, FORM_POW2><<<sgrid, block, 0, s>>>(p);
+            else k_trace_skip_stream<uint16_t, FORM_ANY_N><<<sgrid, block, 0, s>>>(p);
+        }
+        return hipGetLastError();
+    }
+#endif
 #define VRT_LAUNCH_SKIP(T)                                                              \
     (form == FORM_CAPPED ? k_trace_skip<T, FORM_CAPPED><<<grid, block, 0, s>>>(p)         \
      : form == FORM_POW2 ? k_trace_skip<T, FORM_POW2><<<grid, block, 0, s>>>(p)           \

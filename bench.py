@@ -198,6 +198,10 @@ def main():
                     help="frames per gather (pose sharding, N > 1): each rank fills a buffer of this many frames and hands it "
                          "to one gather, which overlaps the tracing of the next buffer; every frame still reaches rank 0 "
                          "inside the timed region.  1 = one gather per frame")
+    ap.add_argument("--gather-pixels", choices=["bgr", "bgra"], default="bgr",
+                    help="what crosses the links of a pose-sharded gather: bgr = three bytes per pixel (the alpha byte, 255 on "
+                         "every path of the shader, is dropped by a pack kernel before the send and restored on rank 0 after "
+                         "it); bgra = the frames as they are")
     ap.add_argument("--time-every", type=int, default=0,
                     help="bracket one frame in this many of the timed region with HIP events as well (0 = none: the two "
                          "events cost about 7 us of stream time per launch; the kernel's duration is measured on "
@@ -269,12 +273,18 @@ def main():
     # pose sharding with N > 1: two buffers of G frames each; the gather of one overlaps the tracing into the other
     G = max(1, args.gather_every)
     gathered = [None, None]
-    batch = None
+    batch = batch3 = arrived = None
+    bgr = args.gather_pixels == "bgr"
+    C_SENT = 3 if bgr else 4            # bytes per pixel on the link
     if multi and not strips:
         batch = [torch.zeros((G, H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+        if bgr:
+            batch3 = [torch.zeros((G, H, W, 3), dtype=torch.uint8, device="cuda") for _ in range(2)]
         if rank == 0:
-            gathered = [[torch.zeros((G, H, W, 4), dtype=torch.uint8, device="cpu" if host else "cuda") for _ in range(world)]
+            gathered = [[torch.zeros((G, H, W, C_SENT), dtype=torch.uint8, device="cpu" if host else "cuda") for _ in range(world)]
                         for _ in range(2)]
+            if bgr:   # the frames of every rank as pixels again
+                arrived = [torch.zeros((world, G, H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
     fill = {"buf": 0, "n": 0, "last": (0, 0)}   # buffer being filled, frames in it, (buffer, slot) of the last frame traced
     if strips:
         pad_rows = sharding.max_strip_rows(H, STRIP_H, world)
@@ -326,9 +336,8 @@ def main():
         elif multi:
             b, j = fill["buf"], fill["n"]
             with torch.cuda.stream(stream):
-                if j == 0 and pending[b] is not None:
-                    pending[b].wait()                # the traces below may overwrite batch[b] only after its gather
-                    pending[b] = None
+                if j == 0:
+                    landed(b)                        # the traces below may overwrite batch[b] only after its gather
                 core.trace_device(cam, W, H, 0, H, {"bgra8": batch[b][j].data_ptr()})
             fill["n"], fill["last"] = j + 1, (b, j)
             if fill["n"] == G:
@@ -336,27 +345,54 @@ def main():
         else:
             core.trace_device(cam, W, H, 0, H, {"bgra8": frames[b].data_ptr()})
 
+    def landed(b):
+        """Called with the context's stream current: that stream waits for the gather of buffer b, and on rank 0 the
+        frames that arrived without their alpha byte become pixels again (unpack kernels on the same stream)."""
+        if pending[b] is None:
+            return
+        if pending[b] is not True:
+            pending[b].wait()
+        pending[b] = None
+        if bgr and rank == 0:
+            for r in range(world):
+                src = gathered[b][r]
+                if host:
+                    src = src.cuda()
+                    torch.cuda.current_stream().synchronize()
+                core.unpack_bgra(src.data_ptr(), arrived[b][r].data_ptr(), G * H * W)
+                if host:
+                    core.sync()
+
     def flush():
         """Hand the buffer being filled to the gather (a partial buffer goes whole: its tail holds older frames)."""
         b = fill["buf"]
         if batch is None or fill["n"] == 0:
             return
+        send = batch[b]
+        if bgr:
+            core.pack_bgr(batch[b].data_ptr(), batch3[b].data_ptr(), G * H * W)   # on the context's stream, behind the traces
+            send = batch3[b]
         if host:
             core.sync()
-            dist.gather(batch[b].cpu(), gathered[b], dst=0)
+            dist.gather(send.cpu(), gathered[b], dst=0)
+            pending[b] = True
         else:
             with torch.cuda.stream(stream):
-                # RCCL gather to rank 0, ordered behind the traces on the context's stream
-                pending[b] = dist.gather(batch[b], gathered[b], dst=0, async_op=True)
+                # RCCL gather to rank 0, ordered behind the traces (and the pack) on the context's stream
+                pending[b] = dist.gather(send, gathered[b], dst=0, async_op=True)
         fill["buf"], fill["n"] = b ^ 1, 0
 
     def fence():
         flush()
         for b in range(2):
             if pending[b] is not None:
-                with torch.cuda.stream(stream):
-                    pending[b].wait()
-                pending[b] = None
+                if batch is not None:
+                    with torch.cuda.stream(stream):
+                        landed(b)
+                else:
+                    with torch.cuda.stream(stream):
+                        pending[b].wait()
+                    pending[b] = None
         core.sync()
         torch.cuda.synchronize()
         if multi:
@@ -394,6 +430,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, kern_max_s = float(t[0].item()), float(t[1].item())
 
+    gather_ok = None
+    if rank == 0 and multi and not strips:
+        # what arrived on rank 0 for every rank's last frame against that rank's pose traced here (the ranks share
+        # the world window: they look from one position with different yaws)
+        lb, lj = fill["last"]
+        check = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+        gather_ok = True
+        for r in range(world):
+            core.trace_device(scenes.cam16(rank_pose(r, world)), W, H, 0, H, {"bgra8": check.data_ptr()})
+            core.sync()
+            got = arrived[lb][r][lj] if bgr else gathered[lb][r][lj]
+            gather_ok = gather_ok and bool(torch.equal(got.cpu(), check.cpu()))
+        core.trace_device(cam, W, H, 0, H, {"bgra8": check.data_ptr()})   # leave the context on this rank's own pose
+        core.sync()
     if rank == 0:
         rays = W * H * args.steps * (1 if strips else world)
         kern_s = kern_ms / 1e3 / max(launches, 1)
@@ -470,6 +520,9 @@ def main():
                                   "steps_sum_equals_oracle_golden": sum_steps == fx["totals"]["steps"] if not strips else None}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(core, cam, steps_np)
+        if multi and not strips:
+            line["gather"] = {"bytes_per_pixel_on_the_link": C_SENT, "frames_per_gather": G,
+                              "last_frame_of_every_rank_equals_its_trace": gather_ok}
         print(json.dumps(line), flush=True)
 
     if strips and multi and rank == 0:
@@ -479,9 +532,7 @@ def main():
         core.sync()
         assert torch.equal(frames[(counter[0] - 1) & 1], whole), "strips did not reassemble to the frame"
     elif multi and rank == 0:
-        # the last gathered frame of rank 0 is its own last frame
-        lb, lj = fill["last"]
-        assert torch.equal(gathered[lb][0][lj].cpu(), batch[lb][lj].cpu()), "gather returned another frame"
+        assert gather_ok, "a gathered frame differs from the frame its rank traced"
     core.close()
     if multi:
         dist.destroy_process_group()

@@ -195,6 +195,15 @@ int vrt_gather(vrt_comm *comm, const void *const *send, size_t bytes_each, void 
 int vrt_gather_strips(vrt_comm *comm, const void *const *packed, void *gathered, void *frame, uint32_t row_bytes,
                       uint32_t h, uint32_t strip_h, uint32_t part_stride_rows);
 
+/* The frame as it travels between GPUs: B, G, R of every pixel without the alpha byte, which is 255 on every path
+ * of the shader (render.comp:9-13), so three quarters of the bytes cross the link that bounds a gathered frame.
+ * vrt_pack_bgr before the send (`pixels` BGRA8 pixels -> 3 * pixels bytes), vrt_unpack_bgra on the receiver (alpha
+ * restored).  `pixels` a multiple of 4; DEVICE memory of the context's GPU, BGRA8 16-byte and BGR8 4-byte aligned,
+ * not overlapping; enqueued on the context's stream.  The reference presents on the device that rendered
+ * (src/graphics/mod.rs:598-611) and has no counterpart. */
+int vrt_pack_bgr(vrt_ctx *ctx, const void *bgra, void *bgr, size_t pixels);
+int vrt_unpack_bgra(vrt_ctx *ctx, const void *bgr, void *bgra, size_t pixels);
+
 /* Page-locked host memory for HOST output planes (and for worlds handed to vrt_upload_world): copies
  * between it and the device run at the bus rate, about three times the rate of pageable memory
  * (1080p BGRA8 frame, kernel + copy: 0.23 ms against 0.54 ms).  Any host memory is accepted by the

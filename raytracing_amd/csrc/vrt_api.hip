@@ -739,6 +739,32 @@ int vrt_assemble_strips(vrt_ctx *c, const void *gathered, void *frame, uint32_t 
     return VRT_OK;
 }
 
+static int check_pixel_buffers(vrt_ctx *c, const void *a, const void *b, size_t pixels)
+{
+    if (!c || !a || !b) return fail(VRT_E_INVALID_ARG, "null argument");
+    if (pixels % 4 != 0) return fail(VRT_E_INVALID_ARG, "pixel count %zu is not a multiple of 4", pixels);
+    if (pixels > ((size_t)1 << 38)) return fail(VRT_E_INVALID_ARG, "pixel count out of range");
+    return VRT_OK;
+}
+
+int vrt_pack_bgr(vrt_ctx *c, const void *bgra, void *bgr, size_t pixels)
+{
+    { int rc = check_pixel_buffers(c, bgra, bgr, pixels); if (rc != VRT_OK) return rc; }
+    if (((uintptr_t)bgra & 15u) || ((uintptr_t)bgr & 3u)) return fail(VRT_E_INVALID_ARG, "bgra must be 16-byte and bgr 4-byte aligned");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(vrt::launch_pack_bgr(bgra, bgr, pixels, c->stream));
+    return VRT_OK;
+}
+
+int vrt_unpack_bgra(vrt_ctx *c, const void *bgr, void *bgra, size_t pixels)
+{
+    { int rc = check_pixel_buffers(c, bgr, bgra, pixels); if (rc != VRT_OK) return rc; }
+    if (((uintptr_t)bgra & 15u) || ((uintptr_t)bgr & 3u)) return fail(VRT_E_INVALID_ARG, "bgra must be 16-byte and bgr 4-byte aligned");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(vrt::launch_unpack_bgra(bgr, bgra, pixels, c->stream));
+    return VRT_OK;
+}
+
 int vrt_alloc_host(vrt_ctx *c, size_t bytes, void **out)
 {
     if (!c || !out || bytes == 0) return fail(VRT_E_INVALID_ARG, "null argument or zero size");

@@ -44,4 +44,46 @@ hipError_t launch_assemble_strips(const void *gathered, void *frame, uint32_t ro
     return assemble<uint8_t>(gathered, frame, row_bytes, h, strip_h, parts, part_stride_rows, s);
 }
 
+// ---------------------------------------------------------------------------
+// The frame as it travels between GPUs: B, G, R of every pixel, without the alpha byte, which is 255 on every path
+// of the shader (render.comp:9-13 stores a = 1).  Three quarters of the bytes over a link that is the bottleneck of
+// a gathered frame.  One lane moves four pixels: 16 bytes in, 12 bytes out, or the other way round.
+__global__ __launch_bounds__(256) void k_pack_bgr(const uint4 *__restrict__ bgra, uint32_t *__restrict__ bgr, size_t quads)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= quads) return;
+    const uint4 p = bgra[i];
+    const uint32_t a = p.x & 0xffffffu, b = p.y & 0xffffffu, c = p.z & 0xffffffu, d = p.w & 0xffffffu;
+    uint32_t *o = bgr + 3 * i;
+    o[0] = a | (b << 24);
+    o[1] = (b >> 8) | (c << 16);
+    o[2] = (c >> 16) | (d << 8);
+}
+
+__global__ __launch_bounds__(256) void k_unpack_bgra(const uint32_t *__restrict__ bgr, uint4 *__restrict__ bgra, size_t quads)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= quads) return;
+    const uint32_t *s = bgr + 3 * i;
+    const uint32_t w0 = s[0], w1 = s[1], w2 = s[2];
+    bgra[i] = make_uint4((w0 & 0xffffffu) | 0xff000000u, (w0 >> 24) | ((w1 & 0xffffu) << 8) | 0xff000000u,
+                         (w1 >> 16) | ((w2 & 0xffu) << 16) | 0xff000000u, (w2 >> 8) | 0xff000000u);
+}
+
+hipError_t launch_pack_bgr(const void *bgra, void *bgr, size_t pixels, hipStream_t s)
+{
+    const size_t quads = pixels / 4;
+    if (quads == 0) return hipSuccess;
+    k_pack_bgr<<<(unsigned)((quads + 255) / 256), 256, 0, s>>>((const uint4 *)bgra, (uint32_t *)bgr, quads);
+    return hipGetLastError();
+}
+
+hipError_t launch_unpack_bgra(const void *bgr, void *bgra, size_t pixels, hipStream_t s)
+{
+    const size_t quads = pixels / 4;
+    if (quads == 0) return hipSuccess;
+    k_unpack_bgra<<<(unsigned)((quads + 255) / 256), 256, 0, s>>>((const uint32_t *)bgr, (uint4 *)bgra, quads);
+    return hipGetLastError();
+}
+
 }  // namespace vrt

@@ -244,6 +244,13 @@ class GraphicsCore:
         L.check(L.lib().vrt_assemble_strips(self._ctx, gathered, frame, row_bytes, h, strip_h, parts,
                                             part_stride_rows))
 
+    def pack_bgr(self, bgra_ptr, bgr_ptr, pixels):
+        """Enqueue BGRA8 -> BGR8 (device addresses; the frame as it travels between GPUs)."""
+        L.check(L.lib().vrt_pack_bgr(self._ctx, bgra_ptr, bgr_ptr, pixels))
+
+    def unpack_bgra(self, bgr_ptr, bgra_ptr, pixels):
+        L.check(L.lib().vrt_unpack_bgra(self._ctx, bgr_ptr, bgra_ptr, pixels))
+
     def sync(self):
         L.check(L.lib().vrt_sync(self._ctx))
 

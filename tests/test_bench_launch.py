@@ -37,12 +37,28 @@ def test_rank_count_that_disagrees_with_gpus_is_refused():
 
 
 @pytest.mark.gpu
-def test_two_ranks_on_one_gpu_over_gloo_print_one_line():
+@pytest.mark.parametrize("pixels,steps", [("bgr", "6"), ("bgra", "2")])  # six steps: a whole buffer of four frames and a partial one
+def test_two_ranks_on_one_gpu_over_gloo_print_one_line(pixels, steps):
     """The whole multi-rank bench (replicated worlds, one pose per rank, framebuffer gather to rank 0), started
-    plainly, with both ranks sharing the one GPU of the box and the gather going through host memory."""
-    p = run_bench("--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--probe", "16")
+    plainly, with both ranks sharing the one GPU of the box and the gather going through host memory.  Rank 0 checks
+    the last frame that arrived from every rank against that rank's pose traced by itself."""
+    p = run_bench("--gpus", "2", "--backend", "gloo", "--steps", steps, "--warmup", "1", "--no-cpu-baseline", "--probe", "16",
+                  "--gather-pixels", pixels)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = json_lines(p.stdout)
     assert len(lines) == 1, p.stdout
-    assert lines[0]["n_gpus"] == 2 and lines[0]["steps"] == 2 and lines[0]["value"] > 0
+    assert lines[0]["n_gpus"] == 2 and lines[0]["steps"] == int(steps) and lines[0]["value"] > 0
     assert lines[0]["scaling"] == "weak" and lines[0]["roofline"]["timed_launches"] >= 16
+    assert lines[0]["gather"] == {"bytes_per_pixel_on_the_link": 3 if pixels == "bgr" else 4, "frames_per_gather": 4,
+                                  "last_frame_of_every_rank_equals_its_trace": True}
+
+
+@pytest.mark.gpu
+def test_single_rank_over_rccl_gathers_packed_pixels():
+    """The N > 1 code path with RCCL itself, as far as one GPU goes: a process group of one rank, the pack kernel, the
+    gather on the context's stream, the unpack kernels behind it."""
+    p = run_bench("--gpus", "1", "--force-gather", "--steps", "9", "--warmup", "2", "--no-cpu-baseline", "--no-literal", "--probe", "16")
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = json_lines(p.stdout)
+    assert len(lines) == 1 and lines[0]["gather"]["last_frame_of_every_rank_equals_its_trace"] is True
+    assert lines[0]["parity"]["bgra8_sha256_equals_oracle_golden"] is True

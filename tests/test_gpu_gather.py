@@ -55,3 +55,29 @@ def test_padded_strip_buffers_are_gathered_behind_the_trace(single_rank_rccl):
             assert torch.equal(frame, whole), i
         with pytest.raises(ValueError):
             sharding.gather_frame(packed, H, strip_h, dst=0, core=g, pad_rows=rows - 1)
+
+
+def test_alpha_is_dropped_and_restored_around_a_transfer():
+    """vrt_pack_bgr / vrt_unpack_bgra on a traced frame (alpha 255 everywhere, as the shader stores it) and on random
+    bytes (the alpha byte is not carried: it comes back as 255)."""
+    W, H, n = 1000, 333, 64   # a pixel count that is a multiple of 4 but not of 256
+    p0 = scenes.pose_b()
+    with GraphicsCore(grid_n=n, voxel_format=VOXEL_PACKED_U8, trace_mode=TRACE_SKIP) as g:
+        g.generate_window(scenes.window_min(p0.get_position(), n))
+        frame = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+        g.trace_device(scenes.cam16(p0), W, H, 0, H, {"bgra8": frame.data_ptr()})
+        noise = torch.randint(0, 256, (H, W, 4), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        for src in (frame, noise):
+            packed = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+            back = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            g.pack_bgr(src.data_ptr(), packed.data_ptr(), W * H)
+            g.unpack_bgra(packed.data_ptr(), back.data_ptr(), W * H)
+            g.sync()
+            assert torch.equal(packed, src[..., :3])
+            assert torch.equal(back[..., :3], src[..., :3]) and bool((back[..., 3] == 255).all())
+        assert torch.equal(frame[..., 3], torch.full((H, W), 255, dtype=torch.uint8, device="cuda"))
+        from raytracing_amd import VrtError
+        with pytest.raises(VrtError):
+            g.pack_bgr(frame.data_ptr(), packed.data_ptr(), W * H - 1)

@@ -202,6 +202,10 @@ def main():
                     help="what crosses the links of a pose-sharded gather: bgr = three bytes per pixel (the alpha byte, 255 on "
                          "every path of the shader, is dropped by a pack kernel before the send and restored on rank 0 after "
                          "it); bgra = the frames as they are")
+    ap.add_argument("--overlap", type=int, default=2,
+                    help="streams the context deals its frames to (vrt_set_frame_overlap): 2 lets the end of one frame's "
+                         "launch run under the beginning of the next; 1 = every launch behind the one before.  Applies to "
+                         "the single-GPU job; with a gather (N > 1) frames stay on one stream")
     ap.add_argument("--time-every", type=int, default=0,
                     help="bracket one frame in this many of the timed region with HIP events as well (0 = none: the two "
                          "events cost about 7 us of stream time per launch; the kernel's duration is measured on "
@@ -265,6 +269,7 @@ def main():
     core.sync()
     build_s = time.perf_counter() - t0
 
+    overlap = 1 if multi else max(1, min(4, args.overlap))
     stream = torch.cuda.ExternalStream(core.stream(), device=torch.device("cuda", local_rank))
     host = args.backend == "gloo"
     # two frame buffers: the gather of frame k overlaps the trace of frame k+1
@@ -399,10 +404,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    core.set_frame_overlap(overlap)
     for _ in range(args.warmup):
         step()
     fence()
-    core.kernel_time_sampling(max(0, min(args.time_every, args.steps)))
+    time_every = args.time_every if args.time_every or overlap == 1 else 8   # overlapped launches: their durations in the region too
+    core.kernel_time_sampling(max(0, min(time_every, args.steps)))
     core.kernel_time_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -411,7 +418,8 @@ def main():
     dt = time.perf_counter() - t0
     region_ms, region_launches = core.kernel_time()
 
-    # the kernel alone: the same launch again, every one bracketed by two HIP events on the context's stream
+    # the kernel alone: the same launch again, one at a time, every one bracketed by two HIP events on the context's stream
+    core.set_frame_overlap(1)
     probe = max(16, args.probe)
     core.kernel_time_sampling(1)
     core.kernel_time_reset()
@@ -462,8 +470,8 @@ def main():
                "frac": traffic / kern_s / 1e9 / HBM_PEAK_GBS if traffic else None,
                "bytes": "FETCH_SIZE x 2 (gfx950 tallies 128-B fills as 64 B) + WRITE_SIZE per launch, profiles/traffic.json"}
         common = {"traffic": traffic, "kernel_ms": kern_s * 1e3, "timed_launches": int(launches),
-                  "timed_how": f"{int(launches)} launches of the same frame right after the timed region, each bracketed by "
-                               "two HIP events on the context's stream",
+                  "timed_how": f"{int(launches)} launches of the same frame right after the timed region, one at a time, each "
+                               "bracketed by two HIP events on the context's stream",
                   "kernel_mrays_s": launch_rays / kern_s / 1e6, "mean_steps_per_ray": sum_steps / launch_rays,
                   "algorithmic_bytes_per_launch": alg_bytes, "reference_equivalent_GBs": ref_equiv_gbs}
         if region_launches:
@@ -474,10 +482,18 @@ def main():
                         "frac": ref_equiv_gbs / HBM_PEAK_GBS, **common}
         else:
             issue = valu_issue_rates(local_rank)
+            # one launch at a time: instructions of a launch / its duration.  Overlapped launches share the GPU, so a
+            # launch's own duration says little; the rate is then instructions of a launch / the region's time per launch
+            per_launch_s = kern_s if overlap == 1 else dt / args.steps
             roofline = {"bound": "valu_issue",
-                        "achieved": valu / kern_s / 1e9 if valu else None, "peak": issue["fma_8_waves"]["ginstr_s"],
+                        "achieved": valu / per_launch_s / 1e9 if valu else None, "peak": issue["fma_8_waves"]["ginstr_s"],
                         "unit": "G wave64 vector instructions/s",
-                        "frac": valu / kern_s / 1e9 / issue["fma_8_waves"]["ginstr_s"] if valu else None,
+                        "frac": valu / per_launch_s / 1e9 / issue["fma_8_waves"]["ginstr_s"] if valu else None,
+                        "achieved_how": ("instructions of a launch / mean duration of a launch (kernel_ms)" if overlap == 1 else
+                                         f"instructions of a launch / time per launch over the timed region (ms_per_step): {overlap} "
+                                         "streams keep launches overlapping, a launch alone takes kernel_ms, in the region "
+                                         "region_sampled_kernel_ms"),
+                        "frac_one_launch_alone": valu / kern_s / 1e9 / issue["fma_8_waves"]["ginstr_s"] if valu else None,
                         "valu_instructions_per_launch": valu,
                         "valu_count_from": "SQ_INSTS_VALU per launch, rocprofv3 --pmc pass of this command (profiles/traffic.json)",
                         "peak_measured": issue, "hbm": hbm, **common}
@@ -498,6 +514,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "frames_in_flight": overlap,
             "config": {"workload": "1920x1080 primary rays over 1024^3 u8 procedural terrain (pose B at y=40.3), "
                                    + ("world replicated per GPU, ONE frame dealt in interleaved 16-row strips, "
                                       "BGRA8 gather + row reorder on rank 0" if strips else

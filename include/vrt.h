@@ -212,8 +212,27 @@ int vrt_unpack_bgra(vrt_ctx *ctx, const void *bgr, void *bgra, size_t pixels);
 int vrt_alloc_host(vrt_ctx *ctx, size_t bytes, void **out);
 int vrt_free_host(vrt_ctx *ctx, void *ptr);
 
-/* Wait for everything enqueued on the context's stream. */
+/* Wait for everything the context has enqueued (on all of its streams). */
 int vrt_sync(vrt_ctx *ctx);
+
+/* Frame overlap, for hosts that trace frames back to back into DEVICE planes (a flythrough, a batch of poses).  One
+ * launch of a frame ends with wavefronts that finish one after the other while the GPU runs empty, and a stream starts
+ * the next launch only when the last of them is done: with `streams` = 2..4 vrt_trace, vrt_trace_strips and
+ * vrt_trace_secondary deal their launches round to that many streams of the context, each with its own scratch, so
+ * that the end of one frame runs under the beginning of the next (1080p over 1024^3: 53.4 -> 48.8 us per frame with
+ * two streams).  1 (the default) is one stream, every launch behind the one before.  With overlap on, frames may
+ * finish in any order: the planes of a frame are complete after vrt_sync, or for work enqueued on vrt_stream(ctx)
+ * after vrt_join(ctx), which makes that stream wait for every trace enqueued so far.  The library's own consumers of
+ * frames (vrt_assemble_strips, vrt_pack_bgr, vrt_unpack_bgra, vrt_gather*) join by themselves, and so does every
+ * change of the world or of its index.  Calls with HOST planes and vrt_trace_static stay on the first stream.  The
+ * reference submits one frame at a time and waits for its fence (src/graphics/mod.rs:598-634); no counterpart.
+ * The call waits for the context's streams; the streams and their scratch are created here, not by a trace. */
+int vrt_set_frame_overlap(vrt_ctx *ctx, uint32_t streams);
+int vrt_join(vrt_ctx *ctx);
+/* The other direction: every stream of the context waits for what has been enqueued on vrt_stream(ctx) so far.  A host
+ * whose own work on that stream still reads a plane calls it before it hands the plane to the next trace, which may run
+ * on another stream. */
+int vrt_fork(vrt_ctx *ctx);
 
 /* Copy the block image back (tests of the generator).  `block_out`: n^3 texels. */
 int vrt_download_world(vrt_ctx *ctx, void *block_out, uint32_t memory);

@@ -69,6 +69,9 @@ SYMBOLS = {
     "vrt_alloc_host": (C.c_int, [_CTX, C.c_size_t, C.POINTER(C.c_void_p)]),
     "vrt_free_host": (C.c_int, [_CTX, C.c_void_p]),
     "vrt_sync": (C.c_int, [_CTX]),
+    "vrt_set_frame_overlap": (C.c_int, [_CTX, C.c_uint32]),
+    "vrt_join": (C.c_int, [_CTX]),
+    "vrt_fork": (C.c_int, [_CTX]),
     "vrt_download_world": (C.c_int, [_CTX, C.c_void_p, C.c_uint32]),
     "vrt_download_index": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_uint32]),
     "vrt_kernel_time": (C.c_int, [_CTX, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),

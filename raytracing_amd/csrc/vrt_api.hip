@@ -37,6 +37,7 @@ int fail(int code, const char *fmt, ...)
     } while (0)
 
 constexpr int kEventRing = 64;
+constexpr int kMaxLanes = 4;  // streams a context deals its frames to (vrt_set_frame_overlap)
 
 constexpr uint32_t kSchedRows = 256;  // = SCHED_MAX_ROWS of the kernels
 constexpr size_t   kSchedHead = 2 + 2 * kSchedRows;
@@ -142,7 +143,16 @@ struct vrt_ctx {
     bool        index_built  = false;    // records and planes describe some earlier state of the whole voxel image
     bool        dirty_box    = false;    // chunks inside [dirty_lo, dirty_hi) (world cells of 4^3 voxels) changed since
     int32_t     dirty_lo[3]  = {0, 0, 0}, dirty_hi[3] = {0, 0, 0};
-    Scratch     own;                     // per-frame tables + dispatch-order slots of this context
+    Scratch     own;                     // per-frame tables + dispatch-order slots of this context (lane 0)
+    // Frame overlap (vrt_set_frame_overlap): traces with DEVICE planes are dealt round to `overlap` lanes, each a stream
+    // with a scratch of its own, so that nothing a launch touches beyond the world and the caller's planes is shared
+    // between launches that run side by side.  Lane 0 is `stream` / `own`.
+    uint32_t    overlap      = 1;
+    uint32_t    next_lane    = 0;
+    hipStream_t lane_stream[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};
+    Scratch     lane_scratch[kMaxLanes];            // [0] unused: lane 0 has `own`
+    hipEvent_t  lane_ev[kMaxLanes]     = {nullptr, nullptr, nullptr, nullptr};
+    bool        lane_busy[kMaxLanes]   = {false, false, false, false};  // launches on the lane since it was last joined
     uint64_t    serial       = 0;        // distinguishes contexts in the dispatch-order history of a shared scratch
     int         pyr_offcy    = -1;       // vertical window offset (cells) the pyramid entries were built for
     bool        skip_valid   = false;
@@ -188,12 +198,58 @@ int drain_events(vrt_ctx *c)
     return VRT_OK;
 }
 
+// The context's first stream waits for everything the other lanes have been given so far: whatever is enqueued on
+// it from here on (a pack or reorder kernel, a copy, the caller's own work, an index update) finds the frames done.
+int join_lanes(vrt_ctx *c)
+{
+    for (uint32_t i = 1; i < c->overlap; ++i) {
+        if (!c->lane_busy[i]) continue;
+        HIP_TRY(hipEventRecord(c->lane_ev[i], c->lane_stream[i]));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->lane_ev[i], 0));
+        c->lane_busy[i] = false;
+    }
+    return VRT_OK;
+}
+
+// The other lanes wait for what the first stream has been given so far (a change of the world or of its index).
+int fork_lanes(vrt_ctx *c)
+{
+    if (c->overlap <= 1) return VRT_OK;
+    HIP_TRY(hipEventRecord(c->lane_ev[0], c->stream));
+    for (uint32_t i = 1; i < c->overlap; ++i) HIP_TRY(hipStreamWaitEvent(c->lane_stream[i], c->lane_ev[0], 0));
+    return VRT_OK;
+}
+
+// The lane of the next trace: lane 0 unless frames overlap and the planes stay on the device.
+uint32_t pick_lane(vrt_ctx *c, bool device_planes)
+{
+    if (c->overlap <= 1 || !device_planes) return 0;
+    const uint32_t lane = c->next_lane;
+    c->next_lane = (lane + 1) % c->overlap;
+    return lane;  // (the caller marks the lane busy once its launch is enqueued: a join before that has nothing to wait for)
+}
+
+int sync_lanes(vrt_ctx *c)
+{
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (uint32_t i = 1; i < c->overlap; ++i) {
+        HIP_TRY(hipStreamSynchronize(c->lane_stream[i]));
+        c->lane_busy[i] = false;
+    }
+    return VRT_OK;
+}
+
+hipStream_t stream_of(vrt_ctx *c, uint32_t lane) { return lane ? c->lane_stream[lane] : c->stream; }
+Scratch &scratch_of(vrt_ctx *c, uint32_t lane) { return lane ? c->lane_scratch[lane] : c->own; }
+
 // Brings the skip structure up to date with the voxel image.  offcy: rem_euclid(lower_y, n) / 4 of the window
 // the next trace uses, or -1 when no camera is known yet (the column-top pyramid, whose entries count levels
 // from the bottom of the window, is then left to the next trace).  Buffers are allocated on the first call
 // and kept; everything else is launches on the context's stream.
 int ensure_skip_structure(vrt_ctx *c, int offcy)
 {
+    const bool work = !c->skip_valid || (offcy >= 0 && c->pyr_offcy != offcy);
+    if (work) { int rc = join_lanes(c); if (rc != VRT_OK) return rc; }  // no trace reads the index while it is rewritten
     if (!c->skip_valid) {
         if (!c->d_cells) { HIP_TRY(hipMalloc(&c->d_cells, cells(c) * 2 * sizeof(uint4))); c->d_pyr = c->d_cells + 1; }
         if (!c->d_tops) HIP_TRY(hipMalloc(&c->d_tops, 2 * (size_t)(c->n / 4) * (c->n / 4) * sizeof(uint16_t)));
@@ -222,6 +278,7 @@ int ensure_skip_structure(vrt_ctx *c, int offcy)
         HIP_TRY(vrt::launch_build_voxel_pyramid(c->d_cells, (int)c->n / 4, offcy, c->d_tops, c->d_pyr, c->stream));
         c->pyr_offcy = offcy;
     }
+    if (work) return fork_lanes(c);
     return VRT_OK;
 }
 
@@ -340,10 +397,10 @@ int attach_row_sched(vrt_ctx *c, Scratch &S, vrt::TraceParams &p, uint32_t kind)
 }
 
 // argument checks, kernel choice and the parameter block shared by every trace entry point
-// (S: the scratch whose tables the launch reads; may_build: the skip structure may be (re)built here, which
+// (S: the scratch whose tables the launch reads, st: the stream the launch goes to; may_build: the skip structure may be (re)built here, which
 // allocates on its first use)
-int prepare_trace(vrt_ctx *c, Scratch &S, bool may_build, const float *cam, uint32_t w, uint32_t h, const vrt::RowMap &rows,
-                  bool need_skip, vrt::TraceParams &p, bool &use_skip)
+int prepare_trace(vrt_ctx *c, Scratch &S, hipStream_t st, bool may_build, const float *cam, uint32_t w, uint32_t h,
+                  const vrt::RowMap &rows, bool need_skip, vrt::TraceParams &p, bool &use_skip)
 {
     if (!c || !cam) return fail(VRT_E_INVALID_ARG, "null argument");
     if (w == 0 || h == 0 || w > 16384 || h > 16384) return fail(VRT_E_INVALID_ARG, "frame size out of range");
@@ -403,7 +460,7 @@ int prepare_trace(vrt_ctx *c, Scratch &S, bool may_build, const float *cam, uint
         float *ncx = S.tables, *ncy = ncx + S.max_dim, *sin2 = ncy + S.max_dim + 1;
         const int32_t base[3] = {p.lo[0] - 4, p.lo[1] - 4, p.lo[2] - 4};
         if (S.tab_w != w || S.tab_h != h || S.tab_sin_len != sin_len || std::memcmp(base, S.tab_base, sizeof base) != 0) {
-            HIP_TRY(vrt::launch_frame_tables(ncx, ncy, sin2, w, h, p.ncy_off, base, sin_len, c->stream));
+            HIP_TRY(vrt::launch_frame_tables(ncx, ncy, sin2, w, h, p.ncy_off, base, sin_len, st));
             S.tab_w = w; S.tab_h = h; S.tab_sin_len = sin_len;
             std::memcpy(S.tab_base, base, sizeof base);
         }
@@ -430,7 +487,10 @@ int do_trace(vrt_ctx *c, const float *cam, uint32_t w, uint32_t h, const vrt::Ro
     if (out->memory != VRT_MEM_HOST && out->memory != VRT_MEM_DEVICE) return fail(VRT_E_INVALID_ARG, "bad outputs.memory");
     vrt::TraceParams p;
     bool use_skip = false;
-    { int rc = prepare_trace(c, c->own, true, cam, w, h, rows, false, p, use_skip); if (rc != VRT_OK) return rc; }
+    const uint32_t lane = pick_lane(c, out->memory == VRT_MEM_DEVICE);
+    const hipStream_t st = stream_of(c, lane);
+    Scratch &S = scratch_of(c, lane);
+    { int rc = prepare_trace(c, S, st, true, cam, w, h, rows, false, p, use_skip); if (rc != VRT_OK) return rc; }
 
     const size_t px = (size_t)rows.rows * w;
     Plane planes[7] = {{0, out->bgra8 ? px * 4 : 0, out->bgra8},       {0, out->voxel ? px * 12 : 0, out->voxel},
@@ -452,13 +512,14 @@ int do_trace(vrt_ctx *c, const float *cam, uint32_t w, uint32_t h, const vrt::Ro
     const bool timed = c->time_every != 0 && c->launch_seq++ % c->time_every == 0;
     if (timed && c->ev_pending == kEventRing) { int rc = drain_events(c); if (rc != VRT_OK) return rc; }
     const int e = c->ev_pending;
-    if (timed) HIP_TRY(hipEventRecord(c->ev0[e], c->stream));
-    if (use_skip) { int rc = attach_row_sched(c, c->own, p, 1); if (rc != VRT_OK) return rc; }
-    if (use_skip) { HIP_TRY(vrt::launch_trace_skip(p, c->voxel_bytes, c->stream)); c->last_kernel = "skip"; }
-    else          { HIP_TRY(vrt::launch_trace_literal(p, c->voxel_bytes, c->stream)); c->last_kernel = "literal"; }
-    if (timed) { HIP_TRY(hipEventRecord(c->ev1[e], c->stream)); c->ev_pending = e + 1; }
+    if (timed) HIP_TRY(hipEventRecord(c->ev0[e], st));
+    if (use_skip) { int rc = attach_row_sched(c, S, p, 1); if (rc != VRT_OK) return rc; }
+    if (use_skip) { HIP_TRY(vrt::launch_trace_skip(p, c->voxel_bytes, st)); c->last_kernel = "skip"; }
+    else          { HIP_TRY(vrt::launch_trace_literal(p, c->voxel_bytes, st)); c->last_kernel = "literal"; }
+    if (timed) { HIP_TRY(hipEventRecord(c->ev1[e], st)); c->ev_pending = e + 1; }
+    if (lane) c->lane_busy[lane] = true;
 
-    if (out->memory == VRT_MEM_HOST) {
+    if (out->memory == VRT_MEM_HOST) {  // (lane 0: its stream)
         for (int i = 0; i < 7; ++i)
             if (planes[i].bytes) HIP_TRY(hipMemcpyAsync(planes[i].host, dev[i], planes[i].bytes, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -539,6 +600,13 @@ int vrt_destroy(vrt_ctx *c)
     if (!c) return VRT_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (int i = 1; i < kMaxLanes; ++i) {
+        if (c->lane_stream[i]) { (void)hipStreamSynchronize(c->lane_stream[i]); (void)hipStreamDestroy(c->lane_stream[i]); }
+        if (c->lane_scratch[i].tables) (void)hipFree(c->lane_scratch[i].tables);
+        if (c->lane_scratch[i].sched) (void)hipFree(c->lane_scratch[i].sched);
+    }
+    for (int i = 0; i < kMaxLanes; ++i)
+        if (c->lane_ev[i]) (void)hipEventDestroy(c->lane_ev[i]);
     for (int i = 0; i < kEventRing; ++i) {
         if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]);
         if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]);
@@ -557,6 +625,7 @@ int vrt_upload_world(vrt_ctx *c, const void *block, const void *dist, uint32_t n
     if (memory != VRT_MEM_HOST && memory != VRT_MEM_DEVICE) return fail(VRT_E_INVALID_ARG, "bad memory kind");
     if (dist && c->format == VRT_VOXEL_PACKED_U8) return fail(VRT_E_INVALID_ARG, "PACKED_U8 has no distance image");
     HIP_TRY(hipSetDevice(c->device));
+    { int rc = join_lanes(c); if (rc != VRT_OK) return rc; }  // (the call ends with a wait for the stream: no fork needed)
     const hipMemcpyKind kind = memory == VRT_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
     HIP_TRY(hipMemcpyAsync(c->d_block, block, texels(c) * (size_t)c->voxel_bytes, kind, c->stream));
     c->dist_nonzero = false;
@@ -584,7 +653,9 @@ int vrt_generate_chunks(vrt_ctx *c, const int32_t *xyz, uint32_t count)
         if (xyz[i] < -lim || xyz[i] > lim) return fail(VRT_E_INVALID_ARG, "chunk position beyond +/-2^20 voxels");
     if (count == 0) return VRT_OK;
     HIP_TRY(hipSetDevice(c->device));
+    { int rc = join_lanes(c); if (rc != VRT_OK) return rc; }  // traces in flight read the voxels; the next trace re-indexes, which forks
     HIP_TRY(vrt::launch_terrain_chunks(c->d_block, c->voxel_bytes, (int)c->n, xyz, count, c->stream));
+    { int rc = fork_lanes(c); if (rc != VRT_OK) return rc; }
     for (uint32_t i = 0; i < count; ++i) {
         const int32_t lo[3] = {xyz[3 * i] * VRT_CHUNK_SIZE, xyz[3 * i + 1] * VRT_CHUNK_SIZE, xyz[3 * i + 2] * VRT_CHUNK_SIZE};
         world_box_changed(c, lo, VRT_CHUNK_SIZE);
@@ -604,8 +675,10 @@ int vrt_generate_window(vrt_ctx *c, const int32_t wmin[3])
     for (int k = 0; k < 3; ++k)
         if (wmin[k] < -(1 << 21) || wmin[k] > (1 << 21)) return fail(VRT_E_INVALID_ARG, "window origin beyond +/-2^21");
     HIP_TRY(hipSetDevice(c->device));
+    { int rc = join_lanes(c); if (rc != VRT_OK) return rc; }
     HIP_TRY(vrt::launch_terrain(c->d_block, c->voxel_bytes, (int)c->n, wmin[0], wmin[1], wmin[2], (int)c->n, (int)c->n,
                                 (int)c->n, c->stream));
+    { int rc = fork_lanes(c); if (rc != VRT_OK) return rc; }
     world_replaced(c);
     return VRT_OK;
 }
@@ -614,7 +687,11 @@ int vrt_reset_distance_field(vrt_ctx *c)
 {
     if (!c) return fail(VRT_E_INVALID_ARG, "null argument");
     HIP_TRY(hipSetDevice(c->device));
-    if (c->d_dist) HIP_TRY(hipMemsetAsync(c->d_dist, 0, texels(c) * sizeof(uint16_t), c->stream));
+    if (c->d_dist) {
+        { int rc = join_lanes(c); if (rc != VRT_OK) return rc; }
+        HIP_TRY(hipMemsetAsync(c->d_dist, 0, texels(c) * sizeof(uint16_t), c->stream));
+        { int rc = fork_lanes(c); if (rc != VRT_OK) return rc; }
+    }
     c->dist_nonzero = false;
     if (c->have_world && c->trace_mode != VRT_TRACE_LITERAL) {
         // (the pyramid is levelled by the next trace, which knows the camera's window)
@@ -652,7 +729,7 @@ int vrt_trace_static(vrt_ctx *c, const float cam[16], uint32_t w, uint32_t h, ui
     vrt::RowMap rows{y0, y1 - y0, 0, 0, 1};
     vrt::TraceParams p;
     bool use_skip = false;
-    { int rc = prepare_trace(c, *S, false, cam, w, h, rows, false, p, use_skip); if (rc != VRT_OK) return rc; }
+    { int rc = prepare_trace(c, *S, c->stream, false, cam, w, h, rows, false, p, use_skip); if (rc != VRT_OK) return rc; }
     p.bgra8 = out->bgra8; p.voxel = out->voxel; p.face = out->face; p.steps = out->steps;
     p.t = out->t; p.hit_point = out->hit_point; p.rgba = out->rgba;
     if (use_skip) { int rc = attach_row_sched(c, *S, p, 1); if (rc != VRT_OK) return rc; }
@@ -671,7 +748,10 @@ int vrt_trace_secondary(vrt_ctx *c, const float cam[16], uint32_t w, uint32_t h,
     vrt::RowMap rows{y0, y1 - y0, 0, 0, 1};
     vrt::TraceParams p;
     bool use_skip = false;
-    { int rc = prepare_trace(c, c->own, true, cam, w, h, rows, true, p, use_skip); if (rc != VRT_OK) return rc; }
+    const uint32_t lane = pick_lane(c, out->memory == VRT_MEM_DEVICE);
+    const hipStream_t st = stream_of(c, lane);
+    Scratch &S = scratch_of(c, lane);
+    { int rc = prepare_trace(c, S, st, true, cam, w, h, rows, true, p, use_skip); if (rc != VRT_OK) return rc; }
     const size_t px = (size_t)rows.rows * w;
     Plane planes[3] = {{0, out->shadow ? px : 0, out->shadow}, {0, out->ao ? px : 0, out->ao},
                        {0, out->sec_steps ? px * 4 : 0, out->sec_steps}};
@@ -687,12 +767,13 @@ int vrt_trace_secondary(vrt_ctx *c, const float cam[16], uint32_t w, uint32_t h,
     const bool timed = c->time_every != 0 && c->launch_seq++ % c->time_every == 0;
     if (timed && c->ev_pending == kEventRing) { int rc = drain_events(c); if (rc != VRT_OK) return rc; }
     const int e = c->ev_pending;
-    if (timed) HIP_TRY(hipEventRecord(c->ev0[e], c->stream));
-    { int rc = attach_row_sched(c, c->own, p, 2); if (rc != VRT_OK) return rc; }
+    if (timed) HIP_TRY(hipEventRecord(c->ev0[e], st));
+    { int rc = attach_row_sched(c, S, p, 2); if (rc != VRT_OK) return rc; }
     HIP_TRY(vrt::launch_trace_secondary(p, c->voxel_bytes, c->knob_secondary_binned, (uint8_t *)dev[0], (uint8_t *)dev[1],
-                                        (uint32_t *)dev[2], c->stream));
+                                        (uint32_t *)dev[2], st));
     c->last_kernel = "secondary";
-    if (timed) { HIP_TRY(hipEventRecord(c->ev1[e], c->stream)); c->ev_pending = e + 1; }
+    if (timed) { HIP_TRY(hipEventRecord(c->ev1[e], st)); c->ev_pending = e + 1; }
+    if (lane) c->lane_busy[lane] = true;
     if (out->memory == VRT_MEM_HOST) {
         for (int i = 0; i < 3; ++i)
             if (planes[i].bytes) HIP_TRY(hipMemcpyAsync(planes[i].host, dev[i], planes[i].bytes, hipMemcpyDeviceToHost, c->stream));
@@ -735,6 +816,7 @@ int vrt_assemble_strips(vrt_ctx *c, const void *gathered, void *frame, uint32_t 
         return fail(VRT_E_INVALID_ARG, "part_stride_rows %u is less than the %u rows of the largest part", part_stride_rows, most);
     if (gathered == frame) return fail(VRT_E_INVALID_ARG, "gathered and frame must not overlap");
     HIP_TRY(hipSetDevice(c->device));
+    { int rc = join_lanes(c); if (rc != VRT_OK) return rc; }
     HIP_TRY(vrt::launch_assemble_strips(gathered, frame, row_bytes, h, strip_h, parts, part_stride_rows, c->stream));
     return VRT_OK;
 }
@@ -752,6 +834,7 @@ int vrt_pack_bgr(vrt_ctx *c, const void *bgra, void *bgr, size_t pixels)
     { int rc = check_pixel_buffers(c, bgra, bgr, pixels); if (rc != VRT_OK) return rc; }
     if (((uintptr_t)bgra & 15u) || ((uintptr_t)bgr & 3u)) return fail(VRT_E_INVALID_ARG, "bgra must be 16-byte and bgr 4-byte aligned");
     HIP_TRY(hipSetDevice(c->device));
+    { int rc = join_lanes(c); if (rc != VRT_OK) return rc; }
     HIP_TRY(vrt::launch_pack_bgr(bgra, bgr, pixels, c->stream));
     return VRT_OK;
 }
@@ -761,6 +844,7 @@ int vrt_unpack_bgra(vrt_ctx *c, const void *bgr, void *bgra, size_t pixels)
     { int rc = check_pixel_buffers(c, bgr, bgra, pixels); if (rc != VRT_OK) return rc; }
     if (((uintptr_t)bgra & 15u) || ((uintptr_t)bgr & 3u)) return fail(VRT_E_INVALID_ARG, "bgra must be 16-byte and bgr 4-byte aligned");
     HIP_TRY(hipSetDevice(c->device));
+    { int rc = join_lanes(c); if (rc != VRT_OK) return rc; }
     HIP_TRY(vrt::launch_unpack_bgra(bgr, bgra, pixels, c->stream));
     return VRT_OK;
 }
@@ -781,7 +865,7 @@ int vrt_free_host(vrt_ctx *c, void *ptr)
     if (!c) return fail(VRT_E_INVALID_ARG, "null argument");
     if (!ptr) return VRT_OK;
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));  // a copy into it may still be in flight
+    { int rc = sync_lanes(c); if (rc != VRT_OK) return rc; }  // a copy into it may still be in flight
     HIP_TRY(hipHostFree(ptr));
     return VRT_OK;
 }
@@ -790,7 +874,46 @@ int vrt_sync(vrt_ctx *c)
 {
     if (!c) return fail(VRT_E_INVALID_ARG, "null argument");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    return sync_lanes(c);
+}
+
+int vrt_join(vrt_ctx *c)
+{
+    if (!c) return fail(VRT_E_INVALID_ARG, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    return join_lanes(c);
+}
+
+int vrt_fork(vrt_ctx *c)
+{
+    if (!c) return fail(VRT_E_INVALID_ARG, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    return fork_lanes(c);
+}
+
+int vrt_set_frame_overlap(vrt_ctx *c, uint32_t streams)
+{
+    if (!c) return fail(VRT_E_INVALID_ARG, "null argument");
+    if (streams < 1 || streams > (uint32_t)kMaxLanes) return fail(VRT_E_INVALID_ARG, "frames overlap on 1..%d streams, not %u", kMaxLanes, streams);
+    HIP_TRY(hipSetDevice(c->device));
+    { int rc = sync_lanes(c); if (rc != VRT_OK) return rc; }
+    if (!c->lane_ev[0]) HIP_TRY(hipEventCreateWithFlags(&c->lane_ev[0], hipEventDisableTiming));
+    for (uint32_t i = 1; i < streams; ++i) {  // lanes are set up once and kept
+        if (!c->lane_stream[i]) HIP_TRY(hipStreamCreateWithFlags(&c->lane_stream[i], hipStreamNonBlocking));
+        if (!c->lane_ev[i]) HIP_TRY(hipEventCreateWithFlags(&c->lane_ev[i], hipEventDisableTiming));
+        Scratch &S = c->lane_scratch[i];
+        if (!S.tables) {
+            S.max_dim = c->own.max_dim; S.sin_cap = c->own.sin_cap; S.sched_capacity = c->own.sched_capacity;
+            HIP_TRY(hipMalloc(&S.tables, S.table_floats() * sizeof(float)));
+        }
+        if (!S.sched) {
+            HIP_TRY(hipMalloc(&S.sched, S.sched_bytes()));
+            HIP_TRY(hipMemsetAsync(S.sched, 0, S.sched_bytes(), c->lane_stream[i]));
+            HIP_TRY(hipStreamSynchronize(c->lane_stream[i]));
+        }
+    }
+    c->overlap = streams;
+    c->next_lane = 0;
     return VRT_OK;
 }
 

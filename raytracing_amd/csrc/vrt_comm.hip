@@ -87,6 +87,10 @@ int exchange(vrt_comm *cm, const void *const *send, const size_t *bytes, const s
 {
     const size_t n = cm->ctx.size();
     const bool   self = cm->self_through_rccl;
+    for (size_t i = 0; i < n; ++i) {  // a context whose frames overlap: its first stream waits for all of them
+        int rc = vrt_join(cm->ctx[i]);
+        if (rc != VRT_OK) return rc;
+    }
     bool any = false;
     for (size_t i = self ? 0 : 1; i < n; ++i) any = any || bytes[i] != 0;
     if (any) {

@@ -254,6 +254,18 @@ class GraphicsCore:
     def sync(self):
         L.check(L.lib().vrt_sync(self._ctx))
 
+    def set_frame_overlap(self, streams):
+        """Deal device-plane traces round to `streams` (1..4) streams so that consecutive frames overlap."""
+        L.check(L.lib().vrt_set_frame_overlap(self._ctx, int(streams)))
+
+    def fork(self):
+        """Every stream of the context waits for what stream() has been given so far."""
+        L.check(L.lib().vrt_fork(self._ctx))
+
+    def join(self):
+        """The context's first stream (stream()) waits for every trace enqueued so far."""
+        L.check(L.lib().vrt_join(self._ctx))
+
     def kernel_time(self):
         ms, n = C.c_double(), C.c_uint64()
         L.check(L.lib().vrt_kernel_time(self._ctx, C.byref(ms), C.byref(n)))

@@ -70,6 +70,9 @@ extern "C" {
     pub fn vrt_alloc_host(ctx: *mut VrtCtx, bytes: usize, out: *mut *mut c_void) -> c_int;
     pub fn vrt_free_host(ctx: *mut VrtCtx, ptr: *mut c_void) -> c_int;
     pub fn vrt_sync(ctx: *mut VrtCtx) -> c_int;
+    pub fn vrt_set_frame_overlap(ctx: *mut VrtCtx, streams: u32) -> c_int;
+    pub fn vrt_join(ctx: *mut VrtCtx) -> c_int;
+    pub fn vrt_fork(ctx: *mut VrtCtx) -> c_int;
     pub fn vrt_download_world(ctx: *mut VrtCtx, block_out: *mut c_void, memory: u32) -> c_int;
     pub fn vrt_download_index(ctx: *mut VrtCtx, cells_out: *mut c_void, pyr_out: *mut c_void, memory: u32) -> c_int;
     pub fn vrt_kernel_time(ctx: *mut VrtCtx, total_ms: *mut f64, launches: *mut u64) -> c_int;

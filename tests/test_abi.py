@@ -53,6 +53,9 @@ def test_argument_validation_without_a_device():
     assert lib.vrt_create(C.byref(cfg), C.byref(ctx)) == L.VRT_E_INVALID_ARG
     assert lib.vrt_destroy(None) == L.VRT_OK
     assert lib.vrt_sync(None) == L.VRT_E_INVALID_ARG
+    assert lib.vrt_set_frame_overlap(None, 2) == L.VRT_E_INVALID_ARG
+    assert lib.vrt_join(None) == L.VRT_E_INVALID_ARG and lib.vrt_fork(None) == L.VRT_E_INVALID_ARG
+    assert lib.vrt_pack_bgr(None, None, None, 4) == L.VRT_E_INVALID_ARG
     assert lib.vrt_generate_chunks(None, None, 0) == L.VRT_E_INVALID_ARG
     assert lib.vrt_download_index(None, None, None, 0) == L.VRT_E_INVALID_ARG
 

@@ -457,13 +457,16 @@ def main():
         kern_s = kern_ms / 1e3 / max(launches, 1)
         name = core.last_kernel_name()
         ref_equiv_gbs = alg_bytes / kern_s / 1e9
-        traffic = valu = None
+        traffic = valu = valu_alone = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf) and not strips:   # the committed counters describe whole-frame launches
             try:
                 prof = json.load(open(tf))
                 traffic = prof.get(name)
                 valu = prof.get(name + "_valu_instructions")
+                if overlap > 1:   # overlapped launches run their rows in plain order, without the bookkeeping of the measured one
+                    valu = prof.get(name + "_plain_order_valu_instructions", valu)
+                    valu_alone = prof.get(name + "_valu_instructions")
             except Exception:
                 traffic = valu = None
         hbm = {"achieved": traffic / kern_s / 1e9 if traffic else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -493,7 +496,7 @@ def main():
                                          f"instructions of a launch / time per launch over the timed region (ms_per_step): {overlap} "
                                          "streams keep launches overlapping, a launch alone takes kernel_ms, in the region "
                                          "region_sampled_kernel_ms"),
-                        "frac_one_launch_alone": valu / kern_s / 1e9 / issue["fma_8_waves"]["ginstr_s"] if valu else None,
+                        "frac_one_launch_alone": (valu_alone or valu) / kern_s / 1e9 / issue["fma_8_waves"]["ginstr_s"] if valu else None,
                         "valu_instructions_per_launch": valu,
                         "valu_count_from": "SQ_INSTS_VALU per launch, rocprofv3 --pmc pass of this command (profiles/traffic.json)",
                         "peak_measured": issue, "hbm": hbm, **common}

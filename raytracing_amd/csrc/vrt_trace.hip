@@ -705,7 +705,15 @@ VRT_DEV bool pixel_of_thread(const PARAMS &P, unsigned by, unsigned tid, unsigne
 {
     const unsigned wave = tid >> 6, lane = tid & 63;
     const unsigned lh = P.tile_log2h, tw = 64u >> lh;
-    col = blockIdx.x * tw + (lane & (tw - 1));
+#ifdef VRT_XCD_STRIPES
+    // An experiment (measured, not adopted): workgroups are dealt round-robin over the eight XCDs, each with an L2 of its
+    // own, so with a row of G workgroups (G a multiple of 8) workgroup x runs on XCD x % 8; tile column
+    // (x % 8) * (G / 8) + x / 8 gives every XCD a vertical stripe of the frame instead of every eighth column.
+    const unsigned G = gridDim.x, bx = (G & 7u) == 0 ? (blockIdx.x & 7u) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+#else
+    const unsigned bx = blockIdx.x;
+#endif
+    col = bx * tw + (lane & (tw - 1));
     q   = ((by * 4 + wave) << lh) + (lane >> (6 - lh));
     if (col >= P.w || q >= P.rows.rows) return false;
     if (P.rows.strip_h == 0) {

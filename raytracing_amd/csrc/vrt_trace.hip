@@ -890,25 +890,28 @@ template <typename PARAMS>
 VRT_DEV void finish_pixel(const PARAMS &P, unsigned gx, unsigned gy, size_t i, const RayHit &H)
 {
     float r, g, b, a = 1.0f;
+    // the packed pixel of the three constant colours (unorm8 of 0.2, 1.0, 0.8; of 0; of 1.0, 0.3, 0.3), so that a
+    // wavefront without a hit -- every tile of sky -- converts nothing
+    unsigned px;
     if (H.hit) {
         const float nk = (float)(-H.sk);
         r = (H.k == 0 ? nk : 0.0f) + 0.5f * shade_sine(P, 0, H.hx);
         g = (H.k == 1 ? nk : 0.0f) + 0.5f * shade_sine(P, 1, H.hy);
         b = (H.k == 2 ? nk : 0.0f) + 0.5f * shade_sine(P, 2, H.hz);
+        px = unorm8(b) | (unorm8(g) << 8) | (unorm8(r) << 16) | 0xff000000u;  // alpha is 1 on every path
     } else if (H.steps >= 1000u) {  // raytrace.glsl:73-75
         r = 0.2f; g = 1.0f; b = 0.8f;
+        px = 0xff33ffccu;
     } else {
         r = g = b = 0.0f;
+        px = 0xff000000u;
     }
     // render.comp:10-12: length(vec2(gid) - vec2(size/2)) < 1.2.  The offsets are integers, so the
     // squared length is an integer and sqrt(.) < 1.2 holds exactly when it is 0 or 1.
     const int dx = (int)gx - (int)(P.w / 2), dy = (int)gy - (int)(P.h / 2);
-    if (dx * dx + dy * dy <= 1) { r = 1.0f; g = 0.3f; b = 0.3f; a = 1.0f; }
+    if (dx * dx + dy * dy <= 1) { r = 1.0f; g = 0.3f; b = 0.3f; a = 1.0f; px = 0xffff4d4du; }
 
-    if (P.bgra8) {
-        const unsigned px = unorm8(b) | (unorm8(g) << 8) | (unorm8(r) << 16) | 0xff000000u;  // alpha is 1 on every path
-        ((unsigned *)P.bgra8)[i] = px;
-    }
+    if (P.bgra8) ((unsigned *)P.bgra8)[i] = px;
     if (P.voxel) { P.voxel[3 * i] = H.vx; P.voxel[3 * i + 1] = H.vy; P.voxel[3 * i + 2] = H.vz; }
     if (P.face) P.face[i] = H.hit ? 2 * H.k + (H.sk < 0 ? 1 : 0) : (H.capped ? -2 : -1);
 #ifdef VRT_DIAG_ITERS

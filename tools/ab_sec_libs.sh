@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of several builds of the library on BASELINE config 5 (tools/ab_secondary.py per build, which also checks that the
+# A/B of several builds of the library on the secondary-ray workload (tools/ab_secondary.py per build, which also checks that the
 # binned kernel's planes equal the per-pixel kernel's).  usage: bash tools/ab_sec_libs.sh rounds lib1.so lib2.so ...
 set -u
 rounds=$1; shift

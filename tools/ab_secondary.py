@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of the two secondary-ray kernels on BASELINE config 5 (1920x1080 primary rays + one shadow and four
+"""A/B of the two secondary-ray kernels on the secondary-ray workload (1920x1080 primary rays + one shadow and four
 ambient-occlusion rays per hit over the 1024^3 u8 terrain) in ONE process: one context per setting of
 VRT_SECONDARY (pixel: every pixel's rays on its own lane; binned: the workgroup's rays staged in LDS and sorted
 by direction class), identical outputs required, interleaved rounds of HIP-event kernel times.

@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 counter passes (one run per pass) for the two secondary-ray kernels on BASELINE config 5.
+# rocprofv3 counter passes (one run per pass) for the two secondary-ray kernels on the secondary-ray workload.
 #   bash tools/profile_secondary_pmc.sh   -> gpurun_out/prof_sec/<variant>/pmc_<pass>/ and a summary per variant
 set -u
 export TMPDIR=/tmp

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""BASELINE config 5 (1080p primary + 5 secondary rays per hit over 1024^3 u8) with one setting of VRT_SECONDARY,
+"""The secondary-ray workload (1080p primary + 5 secondary rays per hit over 1024^3 u8) with one setting of VRT_SECONDARY,
 for profiler runs: usage: sec_run.py pixel|binned [launches]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Distribution of the secondary rays' trip counts (two-phase loop) on BASELINE config 5, from a diagnostic build
+"""Distribution of the secondary rays' trip counts (two-phase loop) on the secondary-ray workload, from a diagnostic build
 of the library (make EXTRA=-DVRT_DIAG_SEC_TRIPS, loaded through VRT_LIB) with VRT_SECONDARY=pixel.
 usage: VRT_LIB=raytracing_amd/ab_diagsec.so sec_trips_probe.py"""
 import os, sys

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where the lanes of the binned secondary-ray kernel go on BASELINE config 5: counters of a diagnostic build
+"""Where the lanes of the binned secondary-ray kernel go on the secondary-ray workload: counters of a diagnostic build
 (tools/build_flags.sh diagutil -DVRT_DIAG_SEC_UTIL; loaded through VRT_LIB), summed over one launch.
 usage: VRT_LIB=raytracing_amd/ab_diagutil.so sec_util_probe.py"""
 import os, sys, json

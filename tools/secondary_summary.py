@@ -10,7 +10,7 @@ def parse(p):
         if m: d[m.group(1)] = float(m.group(2))
     return d
 
-print("BASELINE config 5 (1920x1080 primary rays + one shadow and four ambient-occlusion rays per hit, 1024^3 u8 terrain, pose B at y=40.3)")
+print("Secondary-ray workload (1920x1080 primary rays + one shadow and four ambient-occlusion rays per hit, 1024^3 u8 terrain, pose B at y=40.3)")
 print("rocprofv3 counter passes, one run per pass (tools/profile_secondary_pmc.sh), 8 launches each; kernel times from a separate")
 print("--kernel-trace --stats run of 12 launches.  " + (sys.argv[1] if len(sys.argv) > 1 else ""))
 print()

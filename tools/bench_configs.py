@@ -26,6 +26,20 @@ def timed(g, fn, reps):
     return ms / n
 
 
+def in_flight(g, fns, reps, streams=2):
+    """Wall time per call with the calls dealt to `streams` streams of the context (frames in flight), ms."""
+    g.kernel_time_sampling(0); g.set_frame_overlap(streams)
+    for f in fns: f()
+    g.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        for f in fns: f()
+    g.sync()
+    dt = (time.perf_counter() - t0) / (reps * len(fns))
+    g.set_frame_overlap(1); g.kernel_time_sampling(1)
+    return dt * 1e3
+
+
 def steps_sum(g, cam, w, h):
     st = torch.zeros((h, w), dtype=torch.int32, device="cuda")
     g.trace_device(cam, w, h, 0, h, {"steps": st.data_ptr()}); g.sync()
@@ -57,7 +71,11 @@ for c in which:
         s = steps_sum(g, cam, w, h)
         rows = g.trace_strips(cam, w, h, 16, 3, 8, outputs=("bgra8",))["bgra8"].shape[0]
         ms8 = timed(g, lambda: g.trace_strips_device(cam, w, h, 16, 3, 8, {"bgra8": fr.data_ptr()}), 30)
+        fr2 = torch.zeros_like(fr)
+        ov = in_flight(g, [lambda: g.trace_device(cam, w, h, 0, h, {"bgra8": fr.data_ptr()}),
+                           lambda: g.trace_device(cam, w, h, 0, h, {"bgra8": fr2.data_ptr()})], 30)
         print(json.dumps({"config": 3, "desc": "3840x2160 over 1024^3 u8", "kernel_ms": ms, "mrays_s": w*h/ms/1e3,
+                          "two_frames_in_flight_ms_per_frame": ov, "two_frames_in_flight_mrays_s": w*h/ov/1e3,
                           "alg_GBs": (s + w*h*4)/ms/1e6, "one_of_8_strip_parts_ms": ms8, "part_rows": rows, "build_s": build}))
     elif c == 4:
         n, w, h = 2048, 1920, 1080
@@ -68,7 +86,10 @@ for c in which:
         def fly():
             for cam in cams: g.trace_device(cam, w, h, 0, h, {"bgra8": fr.data_ptr()})
         ms = timed(g, fly, 3)   # per launch
+        frs = [torch.zeros_like(fr) for _ in range(4)]
+        ov = in_flight(g, [(lambda cam=cam, i=i: g.trace_device(cam, w, h, 0, h, {"bgra8": frs[i % 4].data_ptr()})) for i, cam in enumerate(cams)], 3)
         print(json.dumps({"config": 4, "desc": "64 poses x 1920x1080 over 2048^3 u8 (8 GiB)", "kernel_ms_per_pose": ms,
+                          "two_frames_in_flight_ms_per_pose": ov, "two_frames_in_flight_mrays_s": w*h/ov/1e3,
                           "mrays_s": w*h/ms/1e3, "build_s": build}))
     elif c == 5:
         p = scenes.pose_headline(); w, h, n = 1920, 1080, 1024

@@ -204,8 +204,8 @@ def main():
                          "it); bgra = the frames as they are")
     ap.add_argument("--overlap", type=int, default=2,
                     help="streams the context deals its frames to (vrt_set_frame_overlap): 2 lets the end of one frame's "
-                         "launch run under the beginning of the next; 1 = every launch behind the one before.  Applies to "
-                         "the single-GPU job; with a gather (N > 1) frames stay on one stream")
+                         "launch run under the beginning of the next; 1 = every launch behind the one before.  A strip-sharded "
+                         "frame (--shard strips with a gather) stays on one stream")
     ap.add_argument("--time-every", type=int, default=0,
                     help="bracket one frame in this many of the timed region with HIP events as well (0 = none: the two "
                          "events cost about 7 us of stream time per launch; the kernel's duration is measured on "
@@ -269,7 +269,8 @@ def main():
     core.sync()
     build_s = time.perf_counter() - t0
 
-    overlap = 1 if multi else max(1, min(4, args.overlap))
+    # (a strip-sharded frame is one launch per rank and step: nothing to overlap)
+    overlap = 1 if (multi and strips) else max(1, min(4, args.overlap))
     stream = torch.cuda.ExternalStream(core.stream(), device=torch.device("cuda", local_rank))
     host = args.backend == "gloo"
     # two frame buffers: the gather of frame k overlaps the trace of frame k+1
@@ -343,6 +344,7 @@ def main():
             with torch.cuda.stream(stream):
                 if j == 0:
                     landed(b)                        # the traces below may overwrite batch[b] only after its gather
+                    core.fork()                      # ... on whichever of the context's streams they run
                 core.trace_device(cam, W, H, 0, H, {"bgra8": batch[b][j].data_ptr()})
             fill["n"], fill["last"] = j + 1, (b, j)
             if fill["n"] == G:
@@ -375,8 +377,10 @@ def main():
             return
         send = batch[b]
         if bgr:
-            core.pack_bgr(batch[b].data_ptr(), batch3[b].data_ptr(), G * H * W)   # on the context's stream, behind the traces
+            core.pack_bgr(batch[b].data_ptr(), batch3[b].data_ptr(), G * H * W)   # on the context's stream, behind the traces (it joins them)
             send = batch3[b]
+        else:
+            core.join()                              # the context's stream waits for the traces on its other streams
         if host:
             core.sync()
             dist.gather(send.cpu(), gathered[b], dst=0)

@@ -101,7 +101,12 @@ for c in which:
         both = timed(g, lambda: g.trace_secondary_device(cam, w, h, 0, h, sh.data_ptr(), ao.data_ptr(), st.data_ptr()), 30)
         g.trace_device(cam, w, h, 0, h, {"face": fc.data_ptr()}); g.sync()
         hits = int((fc >= 0).sum().item())
+        bufs = [(torch.zeros_like(sh), torch.zeros_like(ao), torch.zeros_like(st)) for _ in range(2)]
+        both2 = in_flight(g, [(lambda b=b: g.trace_secondary_device(cam, w, h, 0, h, b[0].data_ptr(), b[1].data_ptr(), b[2].data_ptr())) for b in bufs], 30)
+        prim2 = in_flight(g, [lambda: g.trace_device(cam, w, h, 0, h, {"bgra8": fr.data_ptr()})] * 2, 30)
         print(json.dumps({"config": 5, "desc": "1080p primary + 5 secondary rays per hit over 1024^3 u8",
+                          "two_frames_in_flight": {"primary_ms": prim2, "primary_plus_secondary_ms": both2,
+                                                   "secondary_mrays_s": 5*hits/max(both2-prim2, 1e-9)/1e3},
                           "primary_ms": prim, "primary_mrays_s": w*h/prim/1e3, "primary_plus_secondary_ms": both,
                           "secondary_rays": 5*hits, "secondary_mrays_s": 5*hits/max(both-prim, 1e-9)/1e3,
                           "mean_secondary_steps": float(st.to(torch.int64).sum().item())/max(5*hits, 1)}))

@@ -53,7 +53,10 @@ for c in which:
         fr = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
         ms = timed(g, lambda: g.trace_device(cam, w, h, 0, h, {"bgra8": fr.data_ptr()}), 50)
         s = steps_sum(g, cam, w, h)
+        frs = [torch.zeros_like(fr) for _ in range(4)]
+        ov = {k: in_flight(g, [(lambda i=i: g.trace_device(cam, w, h, 0, h, {"bgra8": frs[i].data_ptr()})) for i in range(4)], 50, streams=k) for k in (2, 4)}
         print(json.dumps({"config": 1, "desc": "640x480 over 160^3 u16+u16 (the reference's own window)", "kernel_ms": ms,
+                          "frames_in_flight_ms_per_frame": ov,
                           "mrays_s": w*h/ms/1e3, "alg_GBs": (s*2 + w*h*(2+4))/ms/1e6, "build_s": build}))
     elif c == 2:
         p = scenes.pose_b(); w, h, n = 1920, 1080, 256

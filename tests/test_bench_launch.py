@@ -62,3 +62,14 @@ def test_single_rank_over_rccl_gathers_packed_pixels():
     lines = json_lines(p.stdout)
     assert len(lines) == 1 and lines[0]["gather"]["last_frame_of_every_rank_equals_its_trace"] is True
     assert lines[0]["parity"]["bgra8_sha256_equals_oracle_golden"] is True
+
+
+def test_counter_record_the_bench_prices_is_complete():
+    """bench.py takes the kernel's bytes and instruction counts per launch from profiles/traffic.json (a committed
+    counter pass): both launch modes must be there, and the figures must hang together."""
+    t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    for key in ("skip", "skip_valu_instructions", "skip_salu_instructions", "skip_plain_order_valu_instructions"):
+        assert isinstance(t[key], int) and t[key] > 0, key
+    assert t["skip"] == t["_detail"]["fetch_bytes_corrected"] + t["_detail"]["write_bytes"]
+    assert t["_detail"]["write_bytes"] >= 1920 * 1080 * 4             # at least the frame is written
+    assert 0.9 < t["skip_plain_order_valu_instructions"] / t["skip_valu_instructions"] < 1.0

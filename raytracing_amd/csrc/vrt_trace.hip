@@ -1321,7 +1321,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VRT_SEC_WAV
             bins = SEC_BINS - 1;  // the shadow ray
             for (unsigned j = 0; j < 4; ++j) {
                 ao_hash[j] = hsh;
+#if defined(VRT_SEC_ORDER) && VRT_SEC_ORDER == 1      // (measurement builds: steepest first / one class for all)
+                bins |= (hsh >> 28) << (5u * (j + 1u));
+#elif defined(VRT_SEC_ORDER) && VRT_SEC_ORDER == 2
+                bins |= 0u << (5u * (j + 1u));
+#else
                 bins |= (15u - (hsh >> 28)) << (5u * (j + 1u));
+#endif
                 hsh = pcg_hash(hsh); hsh = pcg_hash(hsh);
             }
             for (unsigned j = 0; j < 5; ++j) atomicAdd(&s_count[(bins >> (5u * j)) & 31u], 1u);

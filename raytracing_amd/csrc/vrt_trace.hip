@@ -1336,12 +1336,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VRT_SEC_WAV
     __syncthreads();
     if (tid == 0) {
         unsigned run = 0;
+#if defined(VRT_SEC_ORDER) && VRT_SEC_ORDER == 3      // (measurement build: the shadow rays at the head of the list)
+        s_base[SEC_BINS - 1] = 0; run = s_count[SEC_BINS - 1];
+        for (unsigned b = 0; b < SEC_BINS - 1; ++b) { s_base[b] = run; run += s_count[b]; }
+#else
         for (unsigned b = 0; b < SEC_BINS; ++b) { s_base[b] = run; run += s_count[b]; }
+#endif
         s_total = run;
     }
     __syncthreads();
     // every hit pixel's lane puts its five rays into the list, and the directions of its four ambient-occlusion rays
     // beside them (the list's tail of shadow rays shares one direction and has none stored)
+#if defined(VRT_SEC_ORDER) && VRT_SEC_ORDER == 3
+    const unsigned ao_base = s_count[SEC_BINS - 1];  // list position of the first ambient-occlusion ray
+#else
+    const unsigned ao_base = 0;
+#endif
     if (hit) {
         const int face = (int)s_face[tid];
         s_ray[atomicAdd(&s_base[SEC_BINS - 1], 1u)] = (unsigned short)tid;
@@ -1350,7 +1360,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VRT_SEC_WAV
             s_ray[at] = (unsigned short)(tid | ((j + 1u) << 8));
             float dx, dy, dz;
             ao_dir_from_hash(ao_hash[j], face, dx, dy, dz);
-            s_dir[0][at] = dx; s_dir[1][at] = dy; s_dir[2][at] = dz;
+            s_dir[0][at - ao_base] = dx; s_dir[1][at - ao_base] = dy; s_dir[2][at - ao_base] = dz;
         }
     }
     __syncthreads();
@@ -1403,9 +1413,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VRT_SEC_WAV
                     const unsigned at = first + rank;
                     const unsigned rec = s_ray[at];
                     const unsigned pix = rec & 255u, j = rec >> 8;
-                    const unsigned dat = min(at, 4u * 256u - 1u);
-                    const float sdx = at < n_ao ? s_dir[0][dat] : lightx, sdy = at < n_ao ? s_dir[1][dat] : lighty,
-                                sdz = at < n_ao ? s_dir[2][dat] : lightz;
+                    const bool     is_ao = at - ao_base < n_ao;  // (unsigned: a shadow ray ahead of ao_base wraps round)
+                    const unsigned dat = is_ao ? at - ao_base : 0u;
+                    const float sdx = is_ao ? s_dir[0][dat] : lightx, sdy = is_ao ? s_dir[1][dat] : lighty,
+                                sdz = is_ao ? s_dir[2][dat] : lightz;
                     const float sox = s_org[0][pix], soy = s_org[1][pix], soz = s_org[2][pix];
                     if (FORM == FORM_CAPPED) {  // the one-step-per-trip form is not resumable: the whole ray here
                         RayHit S;

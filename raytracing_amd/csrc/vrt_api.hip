@@ -452,6 +452,8 @@ int prepare_trace(vrt_ctx *c, Scratch &S, hipStream_t st, bool may_build, const 
         p.up[k] = mid + n / 2 - 1;
         int r = p.lo[k] % n;
         p.off[k] = r < 0 ? r + n : r;
+        p.a0[k] = (int)std::floor(cam[12 + k]);  // |position| <= 2^20 was checked above
+        p.thr0[k] = 0.5f - VRT_MARGIN * (std::fabs(cam[12 + k]) + 1.0f);  // (this file is built without contraction, like the kernels)
     }
     p.block = c->d_block;
     p.dist = c->dist_nonzero ? c->d_dist : nullptr;

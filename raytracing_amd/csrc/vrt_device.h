@@ -78,6 +78,42 @@ VRT_DEV float recip_regular(float x)
     return __builtin_fmaf(rem, r, q);
 }
 
+// sqrtf(x) and a / b for operands far from the edges of the float range, as ray generation has them for every
+// ordinary camera: the compiler's own correctly rounded sequences (hardware estimate; for the root two residuals
+// and a step of one ulp either way, for the quotient a Newton step on the reciprocal and two corrections of the
+// quotient, all fused multiply-adds) without the steps around them that rescale operands near the ends of the
+// exponent range and patch up zeros, infinities, NaNs and denormal results.  Those steps do nothing -- the scaling
+// instructions return their operand, the fix-up returns the quotient -- when
+//     2^-80 <= x <= 2^80                                         (sqrt_tame)
+//     2^-40 <= |b| <= 2^40  and  2^-50 <= |a| <= 1.0001 |b|      (div_tame)
+// so the bits are those of sqrtf(x) and a / b there (vrt_selftest_normalize: every x of the range; 3 * 10^9 pairs).  The
+// reciprocal of b and its Newton step depend on b alone: tame_rcp once per denominator, div_tame per numerator.
+VRT_DEV float sqrt_tame(float x)
+{
+    const float y  = __builtin_amdgcn_sqrtf(x);
+    const float ym = __uint_as_float(__float_as_uint(y) - 1u), yp = __uint_as_float(__float_as_uint(y) + 1u);
+    const float em = __builtin_fmaf(-ym, y, x), ep = __builtin_fmaf(-yp, y, x);
+    float r = em <= 0.0f ? ym : y;
+    r = ep > 0.0f ? yp : r;
+    return r;
+}
+
+VRT_DEV float tame_rcp(float b)
+{
+    const float r = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+}
+
+VRT_DEV float div_tame(float a, float b, float rcp_b)
+{
+    const float q0 = a * rcp_b;
+    const float r0 = __builtin_fmaf(-b, q0, a);
+    const float q1 = __builtin_fmaf(r0, rcp_b, q0);
+    const float r1 = __builtin_fmaf(-b, q1, a);
+    return __builtin_fmaf(r1, rcp_b, q1);
+}
+
 // Canonical sine of the shading term (raytrace.glsl:130), binary32 throughout: k = rint(x/pi),
 // reduction against pi = P1 + P2 + P3 with P1 = 3.125 (k*P1 and x - k*P1 are exact for
 // |k| < 2^19), odd Taylor polynomial through r^11.  |error| < 3e-7 for |x| < 2^20.
@@ -105,6 +141,16 @@ VRT_DEV unsigned unorm8(float v)
     v = (v > 0.0f) ? v : 0.0f;
     v = (v < 1.0f) ? v : 1.0f;
     return (unsigned)f2i(floorf(v * 255.0f + 0.5f));
+}
+
+// The same byte, put into byte `at` (0..3) of `word`: the hardware's saturating float -> u8 conversion (NaN -> 0,
+// below 0 -> 0, above 255 -> 255) stands in for the clamp and the conversion, and packs as well.  It rounds to nearest,
+// so the floor stays (its result converts exactly); v * 255 + 0.5 is evaluated as above, and where the clamp would have
+// acted the floored sum lies beyond [0, 255] on the same side and saturates to the same byte.  vrt_selftest_unorm8
+// compares the two for every float.
+VRT_DEV unsigned unorm8_into(float v, unsigned at, unsigned word)
+{
+    return __builtin_amdgcn_cvt_pk_u8_f32(floorf(v * 255.0f + 0.5f), at, word);
 }
 
 }  // namespace vrt

@@ -5,6 +5,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Margin of the exit-point test of the box traversal (vrt_trace.hip), relative to |position| + |origin| + 1
+#ifndef VRT_MARGIN
+#define VRT_MARGIN 0x1.0p-20f
+#endif
+
 namespace vrt {
 
 // Records the thread's error message (vrt_last_error) and returns `code`; shared by the files of the C ABI.
@@ -47,6 +52,10 @@ struct TraceParams {
     // loaded area of this camera (raytrace.glsl:19-24), computed once on the host:
     // lo = floor(ro/32)*32 + 16 - n/2, up = lo + n - 1, off = rem_euclid(lo, n)
     int32_t  lo[3], up[3], off[3];
+    // what every camera ray's set-up shares, worked out once on the host with the kernels' own arithmetic:
+    // a0 = int(floor(ro)), the start voxel (raytrace.glsl:32); thr0 = 0.5 - VRT_MARGIN * (|ro| + 1) per axis
+    int32_t  a0[3];
+    float    thr0[3];
     int32_t  n_pow2_mask;  // n-1 if n is a power of two, else -1
     int32_t  nc_log2;      // log2(n / 4) if n is a power of two
     uint32_t max_steps;
@@ -76,7 +85,7 @@ struct TraceParams {
     // sine of raytrace.glsl:131 for every voxel coordinate a hit point can floor to
     const float *ncx;       // [w]      float(gx) / float(w) - 0.5
     const float *ncy;       // [h + 1]  float(gy) / float(h) - ncy_off, indexed by gy = h - row
-    const float *sin2;      // [3][sin_len]  canon_sin(2 * (sin_base[k] + i))
+    const float *sin2;      // [3][sin_len]  0.5 * canon_sin(2 * (sin_base[k] + i)): the shading term of raytrace.glsl:131, halved (exactly)
     int32_t  sin_base[3];
     uint32_t sin_len;
     // outputs (device pointers, any may be null)

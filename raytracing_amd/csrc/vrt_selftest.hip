@@ -51,6 +51,125 @@ extern "C" int vrt_selftest_recip(int device, unsigned long long out[3])
 }
 
 // ---------------------------------------------------------------------------
+// The short forms of ray generation (sqrt_tame, tame_rcp / div_tame) and the packed UNORM8 conversion (unorm8_into)
+// against the forms they stand in for.
+// ---------------------------------------------------------------------------
+namespace {
+
+__device__ unsigned mix32(unsigned v)
+{
+    v ^= v >> 16; v *= 0x7feb352du; v ^= v >> 15; v *= 0x846ca68bu; v ^= v >> 16;
+    return v;
+}
+
+// thread i checks the 2^12 arguments 2^-80 + (i << 12 | lo) ulps: every float of [2^-80, 2^80)
+__global__ __launch_bounds__(256) void k_check_sqrt_tame(unsigned long long *bad, unsigned *first_bad)
+{
+    const unsigned base = 0x17800000u + ((blockIdx.x * 256u + threadIdx.x) << 12);  // 2^-80 = 0x17800000, 2^80 = 0x67800000
+    unsigned n = 0;
+    for (unsigned lo = 0; lo < 4096u; ++lo) {
+        const float x = __uint_as_float(base + lo);
+        if (__float_as_uint(vrt::sqrt_tame(x)) != __float_as_uint(sqrtf(x))) { if (n++ == 0) atomicMin(first_bad, base + lo); }
+    }
+    if (n) atomicAdd(bad, (unsigned long long)n);
+}
+
+// thread i checks 2^12 pairs (a, b): b of either sign with 2^-40 <= |b| < 2^40 and any mantissa; a = b scaled by a factor
+// that is spread over (0, 1.0001] in the logarithm -- half of the pairs within a factor of two of |b|, where the
+// quotient's rounding is tightest -- with mantissa bits of its own, of either sign, and not below 2^-40
+__global__ __launch_bounds__(256) void k_check_div_tame(unsigned seed, unsigned long long *bad, unsigned long long *tested,
+                                                         unsigned long long *first_bad)
+{
+    const unsigned tid = blockIdx.x * 256u + threadIdx.x;
+    unsigned n = 0, m = 0;
+    for (unsigned j = 0; j < 4096u; ++j) {
+        const unsigned h0 = mix32(seed ^ (tid * 4096u + j)), h1 = mix32(h0 ^ 0x9e3779b9u), h2 = mix32(h1 + 0x85ebca6bu);
+        const unsigned eb = 127u - 40u + (h0 >> 8) % 80u;                       // exponent field of b
+        const float    b = __uint_as_float((h0 << 31) | (eb << 23) | (h1 & 0x7fffffu));
+        const unsigned down = (h2 & 1u) ? (h2 >> 1) % 2u : (h2 >> 1) % 82u;     // a's exponent below b's
+        unsigned       ea = eb - down;
+        float          a = __uint_as_float((h1 & 0x80000000u) | (ea << 23) | (h2 >> 9));
+        if (fabsf(a) > 1.0001f * fabsf(b)) a = __uint_as_float((__float_as_uint(a) & 0x80000000u) | (__float_as_uint(b) & 0x7fffffffu));  // |a| = |b|
+        if (fabsf(a) < 0x1.0p-40f) continue;
+        ++m;
+        const float fast = vrt::div_tame(a, b, vrt::tame_rcp(b)), full = a / b;
+        if (__float_as_uint(fast) != __float_as_uint(full)) {
+            if (n++ == 0) atomicMin(first_bad, ((unsigned long long)__float_as_uint(a) << 32) | __float_as_uint(b));
+        }
+    }
+    if (n) atomicAdd(bad, (unsigned long long)n);
+    atomicAdd(tested, (unsigned long long)m);
+}
+
+// thread i checks the 2^12 floats whose upper 20 bits are i
+__global__ __launch_bounds__(256) void k_check_unorm8(unsigned long long *bad, unsigned *first_bad)
+{
+    const unsigned hi = blockIdx.x * 256u + threadIdx.x;
+    unsigned n = 0;
+    for (unsigned lo = 0; lo < 4096u; ++lo) {
+        const unsigned bits = (hi << 12) | lo;
+        const float    v = __uint_as_float(bits);
+        const unsigned want = vrt::unorm8(v);
+        const unsigned at = bits & 3u;
+        const unsigned got = vrt::unorm8_into(v, at, 0xa5c3e17du);
+        if (got != ((0xa5c3e17du & ~(0xffu << (8u * at))) | (want << (8u * at)))) { if (n++ == 0) atomicMin(first_bad, bits); }
+    }
+    if (n) atomicAdd(bad, (unsigned long long)n);
+}
+
+}  // namespace
+
+// out[0] = floats x of [2^-80, 2^80) with sqrt_tame(x) != sqrtf(x) (all of them are tried); out[1] = pairs with
+// div_tame(a, b, tame_rcp(b)) != a / b among out[2] pseudo-random pairs inside the short form's range (about 3 * 10^9);
+// out[3] = the first offending x, or a << 32 | b (all ones: none).  Returns 0, or the HIP error code.
+extern "C" int vrt_selftest_normalize(int device, unsigned long long out[4])
+{
+    if (!out) return (int)hipErrorInvalidValue;
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return (int)e;
+    unsigned long long *d = nullptr;
+    e = hipMalloc(&d, 5 * sizeof(unsigned long long));
+    if (e != hipSuccess) return (int)e;
+    const unsigned long long init[5] = {0, 0, 0, ~0ull, 0xffffffffull};
+    e = hipMemcpy(d, init, sizeof init, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        k_check_sqrt_tame<<<(0x50000000u >> 12) / 256u, 256>>>(d, reinterpret_cast<unsigned *>(d + 4));
+        k_check_div_tame<<<4096, 256>>>(0x5eed1234u, d + 1, d + 2, d + 3);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    unsigned long long h[5] = {0, 0, 0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    out[0] = h[0]; out[1] = h[1]; out[2] = h[2];
+    out[3] = h[0] ? (h[4] & 0xffffffffull) : h[3];
+    return (int)e;
+}
+
+// out[0] = floats v (all 2^32 bit patterns) for which unorm8_into(v, at, word) differs from unorm8(v) put into byte
+// `at` of `word`; out[1] = the smallest offending bit pattern (0xffffffff: none).  Returns 0, or the HIP error code.
+extern "C" int vrt_selftest_unorm8(int device, unsigned long long out[2])
+{
+    if (!out) return (int)hipErrorInvalidValue;
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return (int)e;
+    unsigned long long *d = nullptr;
+    e = hipMalloc(&d, 2 * sizeof(unsigned long long));
+    if (e != hipSuccess) return (int)e;
+    const unsigned long long init[2] = {0, 0xffffffffull};
+    e = hipMemcpy(d, init, sizeof init, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        k_check_unorm8<<<4096, 256>>>(d, reinterpret_cast<unsigned *>(d + 1));
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(out, d, sizeof init, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e == hipSuccess) out[1] &= 0xffffffffull;
+    return (int)e;
+}
+
+// ---------------------------------------------------------------------------
 // VALU issue rate of the chip: what bounds a kernel that is neither memory nor matrix bound.
 // ---------------------------------------------------------------------------
 namespace {

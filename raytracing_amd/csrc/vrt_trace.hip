@@ -389,18 +389,16 @@ VRT_DEV void traverse_skip(const TraceParams &P, float rox, float roy, float roz
 // whose ray is live, finish() turns the end state into the reference's outputs.  traverse_cells
 // below runs one ray per lane to the end; the stream kernel keeps lanes busy by starting a new ray
 // in a lane whose ray has ended.
-#ifndef VRT_MARGIN
-#define VRT_MARGIN 0x1.0p-20f
-#endif
 template <typename T, bool POW2>
 struct CellRay {
     // per ray constants (mirrored frame)
     float rnx, rny, rnz, dnx, dny, dnz, inx, iny, inz, thr0x, thr0y, thr0z;
     int   lnx, lny, lnz, smx, smy, smz;
-    int   dshift;  // bit 5: the octant byte lives in the record's .w word
+    unsigned dsel;  // byte selector (v_perm_b32) of this ray's octant distance in the record's two distance words
     // state
-    int      wx, wy, wz, w0, k, d, bit, qx, qy, qz;
+    int      wx, wy, wz, w0, k, d, bit;
     unsigned pyr_lo, pyr_hi;  // the cell's word of the voxel-precision column-top pyramid
+    unsigned e;               // that word's entry for the current voxel's level (0: none), kept beside `bit`
     unsigned work, iters;
     uint64_t cur_mask;
     bool     live, hit;
@@ -410,29 +408,54 @@ struct CellRay {
     unsigned dA = 0, dB1 = 0, dB2 = 0, dAx = 0, dBx = 0, dNear = 0, dNearX = 0;  // lanes near a plane; trips that ran the settling code
 #endif
 
+    // entry of the pyramid word for voxel level j = (bit >> 2) & 3: bytes 2j, 2j + 1 of the 64-bit word, cut out by one
+    // byte permute (selector bytes: 0..3 = pyr_lo, 4..7 = pyr_hi, 0x0c = zero).  The selector's constant half is OR-ed
+    // in as a literal of the instruction itself: held in a vector register across the secondary-ray kernel's loop (what
+    // the compiler does with it when it sees a multiply-add) the binned kernel's results came out wrong on the device.
+    VRT_DEV unsigned entry() const
+    {
+        unsigned sel;
+        const unsigned t = 0x0202u * (((unsigned)bit >> 2) & 3u);
+        asm("v_or_b32 %0, 0x0c0c0100, %1" : "=v"(sel) : "v"(t));
+        return __builtin_amdgcn_perm(pyr_hi, pyr_lo, sel);
+    }
+
+    // occupancy of the current voxel in its cell's mask
+    VRT_DEV bool mask_bit() const { return ((unsigned)(cur_mask >> (bit & 63)) & 1u) != 0; }
+
     VRT_DEV void locate(const TraceParams &P)
     {
         const int n = P.n, nc = P.nc;
-        qx = (wx ^ smx) + P.off[0]; qy = (wy ^ smy) + P.off[1]; qz = (wz ^ smz) + P.off[2];
+        int qx = (wx ^ smx) + P.off[0], qy = (wy ^ smy) + P.off[1], qz = (wz ^ smz) + P.off[2];
+        uint4 r;
+        uint2 pw;
         if (POW2) {
-            qx &= P.n_pow2_mask; qy &= P.n_pow2_mask; qz &= P.n_pow2_mask;
+            // (n <= 2048 in this form.)  The cell's coordinates are bit fields of the texel coordinates, which need no
+            // wrap of their own then (the field extraction drops the bits above the grid, off is a multiple of 4), and
+            // the byte offset of the cell's 32 bytes stays below 2^32: one 32-bit offset on the scalar base address,
+            // the pyramid word (rising: bytes 16..23, descending: 24..31) by the sign mask of the y direction.
+            const unsigned L = (unsigned)P.nc_log2;
+            const unsigned cx = __builtin_amdgcn_ubfe((unsigned)qx, 2u, L), cy = __builtin_amdgcn_ubfe((unsigned)qy, 2u, L),
+                           cz = __builtin_amdgcn_ubfe((unsigned)qz, 2u, L);
+            const unsigned at = ((((cz << L) | cy) << L) | cx) << 5;
+            const char *base = reinterpret_cast<const char *>(P.cells);
+            r  = *reinterpret_cast<const uint4 *>(base + at);
+            pw = *reinterpret_cast<const uint2 *>(base + (at | ((unsigned)smy & 8u)) + 16);
         } else {
             qx -= qx >= n ? n : 0; qy -= qy >= n ? n : 0; qz -= qz >= n ? n : 0;
+            const unsigned cell = (unsigned)(((qz >> 2) * nc + (qy >> 2)) * nc + (qx >> 2));
+            const uint4 *rec = P.cells + 2u * cell;  // 32 bytes per cell: the record, then the pyramid words (2 * cell < 2^32)
+            r  = rec[0];
+            pw = reinterpret_cast<const uint2 *>(rec + 1)[smy & 1];  // rising: .x,.y
         }
-        // (shifts for a power of two: the 64-bit multiply-adds of the general form run at quarter rate)
-        const unsigned cell = POW2 ? (unsigned)(((((qz >> 2) << P.nc_log2) | (qy >> 2)) << P.nc_log2) | (qx >> 2))
-                                   : (unsigned)(((qz >> 2) * nc + (qy >> 2)) * nc + (qx >> 2));
-        const uint4 *rec = P.cells + 2u * cell;  // 32 bytes per cell: the record, then the pyramid words (2 * cell < 2^32)
-        const uint4 r = rec[0];
-        const uint2 pw = reinterpret_cast<const uint2 *>(rec + 1)[smy & 1];  // rising: .x,.y
         cur_mask = (uint64_t)r.x | ((uint64_t)r.y << 32);
-        d        = (int)((((dshift & 32) ? r.w : r.z) >> (dshift & 31)) & 0xffu);
-        bit      = ((qz & 3) << 4) | ((qy & 3) << 2) | (qx & 3);  // off is a multiple of 4
+        d        = (int)__builtin_amdgcn_perm(r.w, r.z, dsel);
+        // z * 16 + y * 4 + x of the voxel in its cell (off is a multiple of 4) in bits 0..5; what lies above them is
+        // never looked at (mask_bit, entry)
+        bit      = (int)(((((unsigned)qz << 2) | ((unsigned)qy & 3u)) << 2) | ((unsigned)qx & 3u));
         pyr_lo = pw.x; pyr_hi = pw.y;
+        e = entry();
     }
-
-    // pyramid entry of the current voxel's level (0: none); `bit` carries the level in bits 2..3
-    VRT_DEV unsigned entry() const { return (((bit & 8) ? pyr_hi : pyr_lo) >> ((bit & 4) << 2)) & 0xffffu; }
 
     // Starts (or takes over) a ray at anchor (ax, ay, az) after `steps` iterations of the reference's loop:
     // (floor(ro), 0) for an ordinary ray; the state traverse_degenerate hands over for a ray with zero
@@ -442,7 +465,8 @@ struct CellRay {
     // to the box then keeps, and the margin test never fires.  The stored magnitude carries the sign
     // that lets finish() rebuild the direction bit for bit (sm = -1: rd = -dn).
     // (MAY_FREEZE = false: the caller knows that no component is zero)
-    template <bool MAY_FREEZE>
+    // (CAMERA: the origin is the launch's camera position: the margins of the exit-point test come from the host)
+    template <bool MAY_FREEZE, bool CAMERA = false>
     VRT_DEV void begin(const TraceParams &P, float rox, float roy, float roz, float rdx, float rdy, float rdz,
                        int lox, int loy, int loz, int ax, int ay, int az, unsigned steps)
     {
@@ -459,13 +483,16 @@ struct CellRay {
         } else {  // ray_is_regular holds: the same bits, and the same instructions as in that test
             inx = fabsf(recip_regular(rdx)); iny = fabsf(recip_regular(rdy)); inz = fabsf(recip_regular(rdz));
         }
+        // (the magnitudes as values of their own: left to itself the compiler keeps the signed originals in registers
+        // across the loop and takes the magnitude again in every trip)
+        asm volatile("" : "+v"(dnx), "+v"(dny), "+v"(dnz), "+v"(inx), "+v"(iny), "+v"(inz));
         lnx = px ? lox : -lox; lny = py ? loy : -loy; lnz = pz ? loz : -loz;
         const int oct = (px ? 1 : 0) | (py ? 2 : 0) | (pz ? 4 : 0);
-        dshift = 8 * (oct & 3) + (oct >= 4 ? 32 : 0);
+        dsel = 0x0c0c0c00u | (unsigned)oct;  // byte `oct` of {r.z, r.w}, zero extended
         // margin of the exit-point test, as 0.5 - VRT_MARGIN * (|pos| + |origin| + 1) = thr0 - VRT_MARGIN * |pos|
-        thr0x = zx ? never : 0.5f - VRT_MARGIN * (fabsf(rnx) + 1.0f);
-        thr0y = zy ? never : 0.5f - VRT_MARGIN * (fabsf(rny) + 1.0f);
-        thr0z = zz ? never : 0.5f - VRT_MARGIN * (fabsf(rnz) + 1.0f);
+        thr0x = zx ? never : (CAMERA ? P.thr0[0] : 0.5f - VRT_MARGIN * (fabsf(rnx) + 1.0f));
+        thr0y = zy ? never : (CAMERA ? P.thr0[1] : 0.5f - VRT_MARGIN * (fabsf(rny) + 1.0f));
+        thr0z = zz ? never : (CAMERA ? P.thr0[2] : 0.5f - VRT_MARGIN * (fabsf(rnz) + 1.0f));
         wx = wsub(ax, lox) ^ smx; wy = wsub(ay, loy) ^ smy; wz = wsub(az, loz) ^ smz;
         // every step moves one axis by +1 in the mirrored frame: the step count is the distance from here
         w0 = wx + wy + wz - (int)steps;
@@ -473,12 +500,12 @@ struct CellRay {
         // loop test lower < a + s01 < upper  <=>  wlo <= w <= wlo + n - 3, wlo = 0 (s > 0) or 1 - n (s < 0)
         live = (unsigned)(wx - (smx & (1 - n))) <= span && (unsigned)(wy - (smy & (1 - n))) <= span &&
                (unsigned)(wz - (smz & (1 - n))) <= span;
-        d = 0; pyr_lo = pyr_hi = 0; cur_mask = 0; bit = 0; qx = qy = qz = 0;
+        d = 0; pyr_lo = pyr_hi = 0; e = 0; cur_mask = 0; bit = 0;
         if (live) locate(P);  // the anchor's cell (the start voxel itself is never tested)
     }
 
     // a ray that ended elsewhere: the loop has nothing to do for this lane
-    VRT_DEV void idle() { live = false; hit = false; work = 0; iters = 0; wx = wy = wz = w0 = 0; }
+    VRT_DEV void idle() { live = false; hit = false; work = 0; iters = 0; wx = wy = wz = w0 = 0; d = 0; e = 0; }
 
     // iterations of the reference's loop so far (every step moves one axis by +1 in the mirrored frame)
     VRT_DEV unsigned steps_done() const { return (unsigned)(wx + wy + wz - w0); }
@@ -499,7 +526,6 @@ struct CellRay {
 #ifdef VRT_DIAG_ITERS
         iters += 1u;
 #endif
-        unsigned e = entry();
 #ifdef VRT_DIAG_SEC_UTIL
         dA += (d != 0 || e != 0) ? 1u : 0u;
 #endif
@@ -519,10 +545,9 @@ struct CellRay {
             } else if (e != 0 && (2 << lvl) > d) {  // (measured: better than (1 << lvl) > d and (4 << lvl) > d)
                 const int m4 = (4 << lvl) - 1;
                 // texel of the current anchor up to a multiple of n, which is a multiple of the block width
-                // (qx, qz date from the last cell lookup and may lie some unit steps back)
                 const int ux = (wx ^ smx) + P.off[0], uz = (wz ^ smz) + P.off[2];
-                fwx = m4 >= n - 1 ? whix : min(wx + ((ux ^ ~smx) & m4), whix);
-                fwz = m4 >= n - 1 ? whiz : min(wz + ((uz ^ ~smz) & m4), whiz);
+                fwx = m4 >= n - 1 ? whix : min(wx + (~(ux ^ smx) & m4), whix);
+                fwz = m4 >= n - 1 ? whiz : min(wz + (~(uz ^ smz) & m4), whiz);
                 fwy = smy == 0 ? whiy : min(wy + (int)(e & 0xfffu), whiy);
             } else {
                 const int r4 = (d - 1) << 2;
@@ -561,14 +586,12 @@ struct CellRay {
             wx = k == 0 ? fwx + 1 : min(max(vx, wx), fwx);
             wy = k == 1 ? fwy + 1 : min(max(vy, wy), fwy);
             wz = k == 2 ? fwz + 1 : min(max(vz, wz), fwz);
-            const int wk = k == 0 ? wx : (k == 1 ? wy : wz);
-            const int hk = k == 0 ? whix : (k == 1 ? whiy : whiz);
             // the voxel just entered is tested even when it lies outside the loaded area; the ray
-            // ends after that test (raytrace.glsl:52 comes before the next :43)
+            // ends after that test (raytrace.glsl:52 comes before the next :43).  Only the exit axis can have
+            // left the area (the other two stay inside the box), so "some axis beyond its bound" is that test.
             locate(P);  // a box ends at a cell boundary on its exit axis
-            if (d == 0 && ((cur_mask >> bit) & 1ull)) { hit = true; live = false; }
-            else if (wk > hk) live = false;
-            e = entry();
+            if (d == 0 && mask_bit()) { hit = true; live = false; }
+            else if (((int)(wx > whix) | (int)(wy > whiy) | (int)(wz > whiz)) != 0) live = false;
         }
 #ifdef VRT_DIAG_SEC_UTIL
         dB1 += (!fold && live && d == 0 && e == 0) ? 1u : 0u;
@@ -587,15 +610,16 @@ struct CellRay {
                 const float tx = ((float)(wx + lnx + 1) - rnx) * inx;
                 const float ty = ((float)(wy + lny + 1) - rny) * iny;
                 const float tz = ((float)(wz + lnz + 1) - rnz) * inz;
-                k = argmin3(tx, ty, tz);
-                wx += k == 0 ? 1 : 0; wy += k == 1 ? 1 : 0; wz += k == 2 ? 1 : 0;
-                const int wk = k == 0 ? wx : (k == 1 ? wy : wz);
-                const int hk = k == 0 ? whix : (k == 1 ? whiy : whiz);
+                const int kk = argmin3(tx, ty, tz);
+                k = kk;
+                const int nx = wx + (kk == 0 ? 1 : 0), ny = wy + (kk == 1 ? 1 : 0), nz = wz + (kk == 2 ? 1 : 0);
+                wx = nx; wy = ny; wz = nz;
+                const int nyz = kk == 1 ? ny : nz, wk = kk == 0 ? nx : nyz;  // (locals: selects, not branches)
                 if ((wk & 3) == 0) locate(P);
-                else bit += k == 0 ? dbx : (k == 1 ? dby : dbz);
-                if (d == 0 && ((cur_mask >> bit) & 1ull)) { hit = true; live = false; break; }
-                if (wk > hk) { live = false; break; }
-                if (d != 0 || entry() != 0) break;  // an empty box again: back to phase A
+                else { const int dyz = kk == 1 ? dby : dbz; bit += kk == 0 ? dbx : dyz; e = entry(); }
+                if (d == 0 && mask_bit()) { hit = true; live = false; break; }
+                if (((int)(nx > whix) | (int)(ny > whiy) | (int)(nz > whiz)) != 0) { live = false; break; }
+                if (d != 0 || e != 0) break;  // an empty box again: back to phase A
             }
         }
     }
@@ -605,15 +629,22 @@ struct CellRay {
     // need not stay in registers across the loop.
     VRT_DEV void finish(const TraceParams &P, float rox, float roy, float roz, int lox, int loy, int loz, RayHit &H) const
     {
-        const float rdx = smx ? -dnx : dnx, rdy = smy ? -dny : dny, rdz = smz ? -dnz : dnz;
+        // (members copied to locals: three-way choices between locals compile to selects, between members to branches)
+        const int   sx = smx, sy = smy, sz = smz, kk = k;
+        const float ax_in = inx, ay_in = iny, az_in = inz;
+        const float rdx = sx ? -dnx : dnx, rdy = sy ? -dny : dny, rdz = sz ? -dnz : dnz;
         H.hit = hit ? 1 : 0; H.capped = 0; H.block_id = 0; H.k = 0; H.sk = 0;
-        const int ax = (wx ^ smx) + lox, ay = (wy ^ smy) + loy, az = (wz ^ smz) + loz;
+        const int ax = (wx ^ sx) + lox, ay = (wy ^ sy) + loy, az = (wz ^ sz) + loz;
         if (hit) {
-            H.k = k; H.sk = k == 0 ? (1 | smx) : (k == 1 ? (1 | smy) : (1 | smz));
+            const int   syz = kk == 1 ? sy : sz, sk = kk == 0 ? sx : syz;            // sign mask of the last step's axis
+            const int   ayz = kk == 1 ? ay : az, ak = kk == 0 ? ax : ayz;            // the hit voxel on that axis
+            const float iyz = kk == 1 ? ay_in : az_in, imag = kk == 0 ? ax_in : iyz;  // |1 / rd_k|
+            const float oyz = kk == 1 ? roy : roz, ok = kk == 0 ? rox : oyz;
+            H.k = kk; H.sk = 1 | sk;
             // t as the reference computes it, in the unmirrored frame (see traverse_skip)
-            const int   pk = k == 0 ? ax - smx : (k == 1 ? ay - smy : az - smz);  // the entry plane: a + (s < 0)
-            const float ik = k == 0 ? (smx ? -inx : inx) : (k == 1 ? (smy ? -iny : iny) : (smz ? -inz : inz));  // 1 / rd_k
-            const float th = ((float)pk - (k == 0 ? rox : (k == 1 ? roy : roz))) * ik;
+            const int   pk = ak - sk;                    // the entry plane: a + (s < 0)
+            const float ik = sk ? -imag : imag;          // 1 / rd_k
+            const float th = ((float)pk - ok) * ik;
             H.t = th;
             H.hx = rox + rdx * th; H.hy = roy + rdy * th; H.hz = roz + rdz * th;
             H.block_id = load_block<T>(P, ax, ay, az);
@@ -639,14 +670,16 @@ VRT_DEV bool ray_is_regular(float rdx, float rdy, float rdz)
 #endif
 constexpr int PRIMARY_FOLD = VRT_PRIMARY_FOLD;  // CellRay::trip<FOLD> of rays traced one per lane to the end
 
-// a ray for which ray_is_regular holds
-template <typename T, bool POW2>
+// A ray for which ray_is_regular holds, from the camera (CAMERA: origin = the launch's camera position, whose share
+// of the set-up the host has done) or from anywhere.
+template <typename T, bool POW2, bool CAMERA = false>
 VRT_DEV void traverse_cells_regular(const TraceParams &P, float rox, float roy, float roz, float rdx, float rdy,
                                     float rdz, int lox, int loy, int loz, RayHit &H)
 {
     CellRay<T, POW2> ray;
-    ray.template begin<false>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, f2i_small(floorf(rox)),
-                              f2i_small(floorf(roy)), f2i_small(floorf(roz)), 0u);
+    if (CAMERA) ray.template begin<false, true>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, P.a0[0], P.a0[1], P.a0[2], 0u);
+    else ray.template begin<false>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, f2i_small(floorf(rox)),
+                                   f2i_small(floorf(roy)), f2i_small(floorf(roz)), 0u);
     while (ray.live) ray.template trip<PRIMARY_FOLD>(P);
     ray.finish(P, rox, roy, roz, lox, loy, loz, H);
 }
@@ -833,31 +866,68 @@ VRT_DEV void sched_plan(const TraceParams &P)
     }
 }
 
-// raytrace.glsl:120-123
-VRT_DEV void raygen(const TraceParams &P, unsigned gx, unsigned gy, float &rdx, float &rdy, float &rdz)
+// raytrace.glsl:120-122 without the normalisation: the direction before it and its squared length
+VRT_DEV void raygen_raw(const TraceParams &P, unsigned gx, unsigned gy, float &d0, float &d1, float &d2, float &len2)
 {
     const float fw = (float)P.w, fh = (float)P.h;
     const float ncx = P.ncx ? P.ncx[gx] : (float)gx / fw - 0.5f;
     const float ncy = P.ncy ? P.ncy[gy] : (float)gy / fh - P.ncy_off;
     const float *m = P.m;
-    const float d0 = ((ncx * m[0] + ncy * m[1]) + 1.0f * m[2]) + 1.0f * m[3];
-    const float d1 = ((ncx * m[4] + ncy * m[5]) + 1.0f * m[6]) + 1.0f * m[7];
-    const float d2 = ((ncx * m[8] + ncy * m[9]) + 1.0f * m[10]) + 1.0f * m[11];
-    const float len = sqrtf((d0 * d0 + d1 * d1) + d2 * d2);
+    d0 = ((ncx * m[0] + ncy * m[1]) + 1.0f * m[2]) + 1.0f * m[3];
+    d1 = ((ncx * m[4] + ncy * m[5]) + 1.0f * m[6]) + 1.0f * m[7];
+    d2 = ((ncx * m[8] + ncy * m[9]) + 1.0f * m[10]) + 1.0f * m[11];
+    len2 = (d0 * d0 + d1 * d1) + d2 * d2;
+}
+
+// raytrace.glsl:120-123
+VRT_DEV void raygen(const TraceParams &P, unsigned gx, unsigned gy, float &rdx, float &rdy, float &rdz)
+{
+    float d0, d1, d2, len2;
+    raygen_raw(P, gx, gy, d0, d1, d2, len2);
+    const float len = sqrtf(len2);
     rdx = d0 / len; rdy = d1 / len; rdz = d2 / len;
 }
 
-// sin(floor(hit + 0.001) * 2) of raytrace.glsl:131 for axis k: from the frame's table when the floored
-// coordinate is in it (always, for a hit inside the loaded area), else evaluated
-template <typename PARAMS>
-VRT_DEV float shade_sine(const PARAMS &P, int k, float h)
+// The same direction for the lanes of a wavefront together, and the verdict of ray_is_regular on it.  When every lane's
+// components are tame (2^-40 <= |d_k|, squared length <= 2^80: any camera but one that looks exactly along a coordinate
+// plane through this tile, or one with a matrix of absurd scale) the root and the three quotients are taken in their
+// short forms, which have the same bits there (vrt_device.h), one reciprocal of the length serves the three
+// divisions, and the verdict needs no test: 2^-40 <= len <= 2^40 then, so every |rd_k| is at least 2^-81, none is zero
+// and no reciprocal reaches 2^100.  Any other wavefront takes the general forms, as raygen does.
+VRT_DEV bool raygen_regular(const TraceParams &P, unsigned gx, unsigned gy, float &rdx, float &rdy, float &rdz)
+{
+    float d0, d1, d2, len2;
+    raygen_raw(P, gx, gy, d0, d1, d2, len2);
+    const float least = 0x1.0p-40f;
+    const bool  tame = ((int)(fabsf(d0) >= least) & (int)(fabsf(d1) >= least) & (int)(fabsf(d2) >= least) & (int)(len2 <= 0x1.0p80f)) != 0;
+    if (__builtin_amdgcn_ballot_w64(tame) == __builtin_amdgcn_ballot_w64(true)) {  // every active lane
+        const float len = sqrt_tame(len2), r = tame_rcp(len);
+        rdx = div_tame(d0, len, r); rdy = div_tame(d1, len, r); rdz = div_tame(d2, len, r);
+        return true;
+    }
+    const float len = sqrtf(len2);
+    rdx = d0 / len; rdy = d1 / len; rdz = d2 / len;
+    return ray_is_regular(rdx, rdy, rdz);
+}
+
+// 0.5 * sin(floor(hit + 0.001) * 2) of raytrace.glsl:131 for axis k (halving a float is exact): from the frame's table
+// when the floored coordinate is in it, else evaluated.  IN_WINDOW: the caller's ray is an ordinary one that hit a voxel
+// of the loaded area or the first voxel beyond it, so the hit point lies on that voxel's face up to rounding and its
+// floored coordinate within the table's margin of four voxels; the index is used as it is (held to the table's length,
+// so that no address can leave the table whatever the arithmetic did).
+template <bool IN_WINDOW, typename PARAMS>
+VRT_DEV float shade_half_sine(const PARAMS &P, int k, float h)
 {
     const float f = floorf(h + 0.001f);
+    if (IN_WINDOW) {
+        const unsigned i = (unsigned)(f2i_small(f) - P.sin_base[k]);
+        return P.sin2[(unsigned)k * P.sin_len + min(i, P.sin_len - 1u)];
+    }
     if (P.sin2) {
         const float i = f - (float)P.sin_base[k];  // exact; NaN (a degenerate ray) fails both tests
         if (i >= 0.0f && i < (float)P.sin_len) return P.sin2[(unsigned)k * P.sin_len + (unsigned)f2i_small(i)];
     }
-    return canon_sin(f * 2.0f);
+    return 0.5f * canon_sin(f * 2.0f);
 }
 
 // the same arithmetic, once per frame shape / window position instead of once per pixel
@@ -869,9 +939,9 @@ __global__ __launch_bounds__(256) void k_frame_tables(float *ncx, float *ncy, fl
     if (i < w) ncx[i] = (float)i / fw - 0.5f;
     if (i <= h) ncy[i] = (float)i / fh - ncy_off;
     if (i < sin_len) {
-        sin2[i]               = canon_sin((float)(b0 + (int)i) * 2.0f);
-        sin2[sin_len + i]     = canon_sin((float)(b1 + (int)i) * 2.0f);
-        sin2[2 * sin_len + i] = canon_sin((float)(b2 + (int)i) * 2.0f);
+        sin2[i]               = 0.5f * canon_sin((float)(b0 + (int)i) * 2.0f);
+        sin2[sin_len + i]     = 0.5f * canon_sin((float)(b1 + (int)i) * 2.0f);
+        sin2[2 * sin_len + i] = 0.5f * canon_sin((float)(b2 + (int)i) * 2.0f);
     }
 }
 
@@ -886,30 +956,30 @@ hipError_t launch_frame_tables(float *ncx, float *ncy, float *sin2, uint32_t w, 
 }
 
 // raytrace.glsl:129-133 + render.comp:9-13
-template <typename PARAMS>
+// (IN_WINDOW: see shade_half_sine)
+template <bool IN_WINDOW = false, typename PARAMS>
 VRT_DEV void finish_pixel(const PARAMS &P, unsigned gx, unsigned gy, size_t i, const RayHit &H)
 {
-    float r, g, b, a = 1.0f;
-    // the packed pixel of the three constant colours (unorm8 of 0.2, 1.0, 0.8; of 0; of 1.0, 0.3, 0.3), so that a
-    // wavefront without a hit -- every tile of sky -- converts nothing
+    // The packed pixel, and the shader's float colour only where its plane is asked for.  The three constant colours
+    // are packed constants (unorm8 of 0.2, 1.0, 0.8; of 0; of 1.0, 0.3, 0.3), so a wavefront without a hit -- every
+    // tile of sky -- converts nothing.  Alpha is 1 on every path.
+    float hr = 0.0f, hg = 0.0f, hb = 0.0f;
     unsigned px;
+    const bool teal = H.steps >= 1000u;  // raytrace.glsl:73-75
     if (H.hit) {
         const float nk = (float)(-H.sk);
-        r = (H.k == 0 ? nk : 0.0f) + 0.5f * shade_sine(P, 0, H.hx);
-        g = (H.k == 1 ? nk : 0.0f) + 0.5f * shade_sine(P, 1, H.hy);
-        b = (H.k == 2 ? nk : 0.0f) + 0.5f * shade_sine(P, 2, H.hz);
-        px = unorm8(b) | (unorm8(g) << 8) | (unorm8(r) << 16) | 0xff000000u;  // alpha is 1 on every path
-    } else if (H.steps >= 1000u) {  // raytrace.glsl:73-75
-        r = 0.2f; g = 1.0f; b = 0.8f;
-        px = 0xff33ffccu;
+        const int   k = H.k;
+        hr = (k == 0 ? nk : 0.0f) + shade_half_sine<IN_WINDOW>(P, 0, H.hx);
+        hg = (k == 1 ? nk : 0.0f) + shade_half_sine<IN_WINDOW>(P, 1, H.hy);
+        hb = (k == 2 ? nk : 0.0f) + shade_half_sine<IN_WINDOW>(P, 2, H.hz);
+        px = unorm8_into(hb, 0u, unorm8_into(hg, 1u, unorm8_into(hr, 2u, 0xff000000u)));
     } else {
-        r = g = b = 0.0f;
-        px = 0xff000000u;
+        px = teal ? 0xff33ffccu : 0xff000000u;
     }
-    // render.comp:10-12: length(vec2(gid) - vec2(size/2)) < 1.2.  The offsets are integers, so the
-    // squared length is an integer and sqrt(.) < 1.2 holds exactly when it is 0 or 1.
-    const int dx = (int)gx - (int)(P.w / 2), dy = (int)gy - (int)(P.h / 2);
-    if (dx * dx + dy * dy <= 1) { r = 1.0f; g = 0.3f; b = 0.3f; a = 1.0f; px = 0xffff4d4du; }
+    // render.comp:10-12: length(vec2(gid) - vec2(size/2)) < 1.2.  The offsets are integers: the length is below 1.2
+    // exactly when the squared length is 0 or 1, that is when |dx| + |dy| <= 1.
+    const bool cross = __sad(gy, P.h / 2, __sad(gx, P.w / 2, 0u)) <= 1u;
+    if (cross) px = 0xffff4d4du;
 
     if (P.bgra8) ((unsigned *)P.bgra8)[i] = px;
     if (P.voxel) { P.voxel[3 * i] = H.vx; P.voxel[3 * i + 1] = H.vy; P.voxel[3 * i + 2] = H.vz; }
@@ -921,7 +991,11 @@ VRT_DEV void finish_pixel(const PARAMS &P, unsigned gx, unsigned gy, size_t i, c
 #endif
     if (P.t) P.t[i] = H.t;
     if (P.hit_point) { P.hit_point[3 * i] = H.hx; P.hit_point[3 * i + 1] = H.hy; P.hit_point[3 * i + 2] = H.hz; }
-    if (P.rgba) { P.rgba[4 * i] = r; P.rgba[4 * i + 1] = g; P.rgba[4 * i + 2] = b; P.rgba[4 * i + 3] = a; }
+    if (P.rgba) {
+        float r = H.hit ? hr : (teal ? 0.2f : 0.0f), g = H.hit ? hg : (teal ? 1.0f : 0.0f), b = H.hit ? hb : (teal ? 0.8f : 0.0f);
+        if (cross) { r = 1.0f; g = 0.3f; b = 0.3f; }
+        P.rgba[4 * i] = r; P.rgba[4 * i + 1] = g; P.rgba[4 * i + 2] = b; P.rgba[4 * i + 3] = 1.0f;
+    }
 }
 
 template <typename T, bool HAS_DIST>
@@ -970,15 +1044,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         const long long d0 = wall_clock64();
 #endif
         float rdx, rdy, rdz;
-        raygen(P, col, P.h - row, rdx, rdy, rdz);
+        bool  regular = true;  // (the capped form sorts its rays out itself)
+        if (FORM == FORM_CAPPED) raygen(P, col, P.h - row, rdx, rdy, rdz);
+        else regular = raygen_regular(P, col, P.h - row, rdx, rdy, rdz);
         const float rox = P.m[12], roy = P.m[13], roz = P.m[14];
         // loaded area (raytrace.glsl:19-24), evaluated once per frame on the host
         const int lox = P.lo[0], loy = P.lo[1], loz = P.lo[2], upx = P.up[0], upy = P.up[1], upz = P.up[2];
-        const bool regular = FORM == FORM_CAPPED || ray_is_regular(rdx, rdy, rdz);
         RayHit H;
         if (regular) {
             if (FORM == FORM_CAPPED) traverse_skip<T>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
-            else traverse_cells_regular<T, FORM == FORM_POW2>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, H);
+            else traverse_cells_regular<T, FORM == FORM_POW2, true>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, H);
             work = H.work;
         }
         // What follows the traversal loop takes nothing over from before it but the ray's result: the pixel's
@@ -988,7 +1063,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         const KernargParams &K = *kernarg_again();
         pixel_of_thread(K, by, opaque(threadIdx.x), col, q, row);
         const unsigned gx = col, gy = K.h - row;
-        if (regular) finish_pixel(K, gx, gy, (size_t)q * K.w + col, H);
+        // (the capped form also traces rays that are not ordinary ones)
+        if (regular) finish_pixel<FORM != FORM_CAPPED>(K, gx, gy, (size_t)q * K.w + col, H);
         if (!regular)  // (the builtin is only valid in the kernel itself; TraceParams sits at offset 0 of the segment)
             work = degenerate_pixel<T, FORM>((const TraceParams *)__builtin_amdgcn_kernarg_segment_ptr(), gx, gy, q);
 #ifdef VRT_DIAG_CLOCK
@@ -1057,8 +1133,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VRT_STREAM_
                     ++j;
                     if (by >= total_rows || !pixel_of_thread(P, by, tid, col, q, row)) continue;
                     float rdx, rdy, rdz;
-                    raygen(P, col, P.h - row, rdx, rdy, rdz);
-                    if (ray_is_regular(rdx, rdy, rdz)) {
+                    if (raygen_regular(P, col, P.h - row, rdx, rdy, rdz)) {
                         ray.template begin<false>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, f2i_small(floorf(rox)),
                                                   f2i_small(floorf(roy)), f2i_small(floorf(roz)), 0u);
                         holding = true;
@@ -1153,7 +1228,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     if (pixel_of_thread(P, by, threadIdx.x, col, q, row)) {
         const unsigned gx = col, gy = P.h - row;
         float rdx, rdy, rdz;
-        raygen(P, gx, gy, rdx, rdy, rdz);
+        bool  regular = true;
+        if (FORM == FORM_CAPPED) raygen(P, gx, gy, rdx, rdy, rdz);
+        else regular = raygen_regular(P, gx, gy, rdx, rdy, rdz);
         const float rox = P.m[12], roy = P.m[13], roz = P.m[14];
         // loaded area (raytrace.glsl:19-24), evaluated once per frame on the host
         const int lox = P.lo[0], loy = P.lo[1], loz = P.lo[2], upx = P.up[0], upy = P.up[1], upz = P.up[2];
@@ -1161,8 +1238,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         RayHit H;
         if (FORM == FORM_CAPPED) {
             traverse_skip<T>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
-        } else if (ray_is_regular(rdx, rdy, rdz)) {
-            traverse_cells_regular<T, FORM == FORM_POW2>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, H);
+        } else if (regular) {
+            traverse_cells_regular<T, FORM == FORM_POW2, true>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, H);
         } else {
             float hp[3];
             const unsigned r = degenerate_primary<T, FORM>(params, gx, gy, hp);
@@ -1292,15 +1369,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VRT_SEC_WAV
     if (inside) {
         const unsigned gx = col, gy = P.h - row;
         float rdx, rdy, rdz;
-        raygen(P, gx, gy, rdx, rdy, rdz);
+        bool  regular = true;
+        if (FORM == FORM_CAPPED) raygen(P, gx, gy, rdx, rdy, rdz);
+        else regular = raygen_regular(P, gx, gy, rdx, rdy, rdz);
         const float rox = P.m[12], roy = P.m[13], roz = P.m[14];
         const int lox = P.lo[0], loy = P.lo[1], loz = P.lo[2], upx = P.up[0], upy = P.up[1], upz = P.up[2];
         const TraceParams *params = (const TraceParams *)__builtin_amdgcn_kernarg_segment_ptr();  // P sits at offset 0
         RayHit H;
         if (FORM == FORM_CAPPED) {
             traverse_skip<T>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
-        } else if (ray_is_regular(rdx, rdy, rdz)) {
-            traverse_cells_regular<T, FORM == FORM_POW2>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, H);
+        } else if (regular) {
+            traverse_cells_regular<T, FORM == FORM_POW2, true>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, H);
         } else {
             float hp[3];
             const unsigned r = degenerate_primary<T, FORM>(params, gx, gy, hp);
@@ -1487,7 +1566,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VRT_SEC_WAV
 
 static int trace_form(const TraceParams &p)
 {
-    return p.need_cap ? FORM_CAPPED : (p.n_pow2_mask >= 0 ? FORM_POW2 : FORM_ANY_N);
+    // (FORM_POW2 addresses the cell records by 32-bit byte offsets: 32 * (n / 4)^3 <= 2^32)
+    return p.need_cap ? FORM_CAPPED : (p.n_pow2_mask >= 0 && p.n <= 2048 ? FORM_POW2 : FORM_ANY_N);
 }
 
 static dim3 trace_grid(const TraceParams &p)

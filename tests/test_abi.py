@@ -152,10 +152,41 @@ def test_rust_graphics_module_keeps_the_reference_signatures():
         assert name in shim, name
 
 
+def integration_snippet():
+    """The Rust block of INTEGRATION.md section 3."""
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    section = md[md.index("## 3. `GraphicsCore` keeps its signatures"):md.index("## 4. ")]
+    blocks = re.findall(r"```rust\n(.*?)```", section, re.S)
+    assert len(blocks) == 1
+    return blocks[0]
+
+
+def test_integration_text_is_the_rust_module():
+    """One text for the Rust boundary: the snippet a maintainer reads in INTEGRATION.md is rust/src/graphics/mod.rs with
+    the event loop's body elided -- every line of it is a line of that file, in order -- and it matches each of the
+    reference's signatures by itself."""
+    snippet = integration_snippet()
+    module = open(os.path.join(ROOT, "rust", "src", "graphics", "mod.rs")).read().split("\n")
+    at = 0
+    for line in snippet.split("\n"):
+        if not line.strip() or line.strip().startswith("// ...") or line.strip().startswith("//     "):
+            continue
+        while at < len(module) and module[at] != line:
+            at += 1
+        assert at < len(module), f"INTEGRATION.md line not in rust/src/graphics/mod.rs (or out of order): {line!r}"
+        at += 1
+    squeezed = squeeze(snippet)
+    for pattern, _ in REFERENCE_SURFACE:
+        assert re.search(pattern, squeezed), pattern
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert "FrameToken" not in md and "fresh_frame_token" not in md
+
+
 def test_selftest_library_loads():
     import ctypes as C
     import os
     from raytracing_amd import _lib as L
     lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(L.__file__)), "libvrt_selftest.so"))
-    for name in ("vrt_selftest_recip", "vrt_selftest_valu_rate", "vrt_selftest_kernarg"):
+    for name in ("vrt_selftest_recip", "vrt_selftest_valu_rate", "vrt_selftest_kernarg", "vrt_selftest_normalize",
+                 "vrt_selftest_unorm8"):
         assert hasattr(lib, name), name

@@ -93,6 +93,30 @@ def _selftest_lib():
     return C.CDLL(os.path.join(os.path.dirname(os.path.abspath(L.__file__)), "libvrt_selftest.so"))
 
 
+def test_short_square_root_and_division_of_ray_generation_are_the_full_ones():
+    """sqrt_tame against sqrtf for every float of [2^-80, 2^80), and div_tame against a / b for about 3 * 10^9 pseudo-random
+    pairs inside the range the kernels use it in (2^-40 <= |b| < 2^40, 2^-40 <= |a| <= 1.0001 |b|, half of them within a
+    factor of two of |b|): identical bits (tolerance 0)."""
+    lib = _selftest_lib()
+    lib.vrt_selftest_normalize.restype = C.c_int
+    lib.vrt_selftest_normalize.argtypes = [C.c_int, C.POINTER(C.c_ulonglong)]
+    out = (C.c_ulonglong * 4)()
+    assert lib.vrt_selftest_normalize(0, out) == 0
+    assert out[2] > 2 ** 31, f"only {out[2]} pairs tested"
+    assert (out[0], out[1]) == (0, 0), f"sqrt differs for {out[0]} arguments, a / b for {out[1]} of {out[2]} pairs; first 0x{out[3]:x}"
+
+
+def test_packed_unorm8_conversion_is_the_canonical_one_for_every_float():
+    """unorm8_into (floor(v * 255 + 0.5) through the hardware's saturating float -> u8 conversion, packed into a byte of
+    a word) against unorm8 (clamp, floor, convert) for all 2^32 bit patterns, in all four byte positions."""
+    lib = _selftest_lib()
+    lib.vrt_selftest_unorm8.restype = C.c_int
+    lib.vrt_selftest_unorm8.argtypes = [C.c_int, C.POINTER(C.c_ulonglong)]
+    out = (C.c_ulonglong * 2)()
+    assert lib.vrt_selftest_unorm8(0, out) == 0
+    assert out[0] == 0, f"{out[0]} floats convert differently; first 0x{out[1]:08x}"
+
+
 def test_kernel_argument_segment_starts_with_the_parameter_block():
     """The trace kernels pass their out-of-line code a pointer to the kernel-argument segment in place of a
     copy of TraceParams (vrt_trace.hip: degenerate_pixel, degenerate_primary, degenerate_ray).  That holds

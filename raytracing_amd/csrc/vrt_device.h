@@ -30,6 +30,26 @@ VRT_DEV int f2i(float x)
 // float -> int for values known to be finite and far inside the int range.
 VRT_DEV int f2i_small(float x) { return (int)x; }
 
+// int(floor(x)) in one instruction, for values known to be finite and far inside the int range (the hardware conversion
+// that rounds toward minus infinity; vrt_selftest_floor_convert compares it with the two-step form for every float
+// of magnitude below 2^31).
+VRT_DEV int f2i_floor(float x)
+{
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
+// |a| * m + |b| as one fused multiply-add with the magnitudes taken by the instruction's own operand modifiers (written
+// out because the compiler pairs two such operations into a packed instruction, which has no magnitude modifier, and
+// pays four extra instructions for the pair).  The result only steers which of two exact paths a lane takes.
+VRT_DEV float fma_abs(float a, float m, float b)
+{
+    float r;
+    asm("v_fma_f32 %0, |%1|, %2, |%3|" : "=v"(r) : "v"(a), "s"(m), "v"(b));
+    return r;
+}
+
 // The same value, as far as the optimiser can tell a new one: what is computed from it is computed again
 // instead of being kept in registers from an earlier computation.
 VRT_DEV unsigned opaque(unsigned v)

@@ -117,7 +117,44 @@ __global__ __launch_bounds__(256) void k_check_unorm8(unsigned long long *bad, u
     if (n) atomicAdd(bad, (unsigned long long)n);
 }
 
+// thread i checks the 2^12 floats whose upper 20 bits are i
+__global__ __launch_bounds__(256) void k_check_floor_convert(unsigned long long *bad, unsigned *first_bad)
+{
+    const unsigned hi = blockIdx.x * 256u + threadIdx.x;
+    unsigned n = 0;
+    for (unsigned lo = 0; lo < 4096u; ++lo) {
+        const unsigned bits = (hi << 12) | lo;
+        const float    x = __uint_as_float(bits);
+        if (!(fabsf(x) < 0x1.0p31f)) continue;
+        if (vrt::f2i_floor(x) != (int)floorf(x)) { if (n++ == 0) atomicMin(first_bad, bits); }
+    }
+    if (n) atomicAdd(bad, (unsigned long long)n);
+}
+
 }  // namespace
+
+// out[0] = floats x of magnitude below 2^31 (all of them are tried) with f2i_floor(x) != (int)floorf(x); out[1] = the
+// smallest offending bit pattern (0xffffffff: none).  Returns 0, or the HIP error code.
+extern "C" int vrt_selftest_floor_convert(int device, unsigned long long out[2])
+{
+    if (!out) return (int)hipErrorInvalidValue;
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return (int)e;
+    unsigned long long *d = nullptr;
+    e = hipMalloc(&d, 2 * sizeof(unsigned long long));
+    if (e != hipSuccess) return (int)e;
+    const unsigned long long init[2] = {0, 0xffffffffull};
+    e = hipMemcpy(d, init, sizeof init, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        k_check_floor_convert<<<4096, 256>>>(d, reinterpret_cast<unsigned *>(d + 1));
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(out, d, sizeof init, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e == hipSuccess) out[1] &= 0xffffffffull;
+    return (int)e;
+}
 
 // out[0] = floats x of [2^-80, 2^80) with sqrt_tame(x) != sqrtf(x) (all of them are tried); out[1] = pairs with
 // div_tame(a, b, tame_rcp(b)) != a / b among out[2] pseudo-random pairs inside the short form's range (about 3 * 10^9);

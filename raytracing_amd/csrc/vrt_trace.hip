@@ -393,7 +393,7 @@ template <typename T, bool POW2>
 struct CellRay {
     // per ray constants (mirrored frame)
     float rnx, rny, rnz, dnx, dny, dnz, inx, iny, inz, thr0x, thr0y, thr0z;
-    int   lnx, lny, lnz, smx, smy, smz;
+    int   lnx, lny, lnz, ln1x, ln1y, ln1z, smx, smy, smz;  // (ln1 = ln + 1)
     unsigned dsel;  // byte selector (v_perm_b32) of this ray's octant distance in the record's two distance words
     // state
     int      wx, wy, wz, w0, k, d, bit;
@@ -408,17 +408,18 @@ struct CellRay {
     unsigned dA = 0, dB1 = 0, dB2 = 0, dAx = 0, dBx = 0, dNear = 0, dNearX = 0;  // lanes near a plane; trips that ran the settling code
 #endif
 
-    // entry of the pyramid word for voxel level j = (bit >> 2) & 3: bytes 2j, 2j + 1 of the 64-bit word, cut out by one
+    // entry of the pyramid word for voxel level j (0..3): bytes 2j, 2j + 1 of the 64-bit word, cut out by one
     // byte permute (selector bytes: 0..3 = pyr_lo, 4..7 = pyr_hi, 0x0c = zero).  The selector's constant half is OR-ed
     // in as a literal of the instruction itself: held in a vector register across the secondary-ray kernel's loop (what
     // the compiler does with it when it sees a multiply-add) the binned kernel's results came out wrong on the device.
-    VRT_DEV unsigned entry() const
+    VRT_DEV unsigned entry_of(unsigned j) const
     {
         unsigned sel;
-        const unsigned t = 0x0202u * (((unsigned)bit >> 2) & 3u);
+        const unsigned t = 0x0202u * j;
         asm("v_or_b32 %0, 0x0c0c0100, %1" : "=v"(sel) : "v"(t));
         return __builtin_amdgcn_perm(pyr_hi, pyr_lo, sel);
     }
+    VRT_DEV unsigned entry() const { return entry_of(((unsigned)bit >> 2) & 3u); }
 
     // occupancy of the current voxel in its cell's mask
     VRT_DEV bool mask_bit() const { return ((unsigned)(cur_mask >> (bit & 63)) & 1u) != 0; }
@@ -452,9 +453,11 @@ struct CellRay {
         d        = (int)__builtin_amdgcn_perm(r.w, r.z, dsel);
         // z * 16 + y * 4 + x of the voxel in its cell (off is a multiple of 4) in bits 0..5; what lies above them is
         // never looked at (mask_bit, entry)
-        bit      = (int)(((((unsigned)qz << 2) | ((unsigned)qy & 3u)) << 2) | ((unsigned)qx & 3u));
+        unsigned lvl = (unsigned)qy & 3u;
+        asm("" : "+v"(lvl));  // (kept whole: the compiler would spread the shifts over the three fields, two instructions more)
+        bit      = (int)(((((unsigned)qz << 2) | lvl) << 2) | ((unsigned)qx & 3u));
         pyr_lo = pw.x; pyr_hi = pw.y;
-        e = entry();
+        e = entry_of(lvl);
     }
 
     // Starts (or takes over) a ray at anchor (ax, ay, az) after `steps` iterations of the reference's loop:
@@ -487,6 +490,7 @@ struct CellRay {
         // across the loop and takes the magnitude again in every trip)
         asm volatile("" : "+v"(dnx), "+v"(dny), "+v"(dnz), "+v"(inx), "+v"(iny), "+v"(inz));
         lnx = px ? lox : -lox; lny = py ? loy : -loy; lnz = pz ? loz : -loz;
+        ln1x = lnx + 1; ln1y = lny + 1; ln1z = lnz + 1;
         const int oct = (px ? 1 : 0) | (py ? 2 : 0) | (pz ? 4 : 0);
         dsel = 0x0c0c0c00u | (unsigned)oct;  // byte `oct` of {r.z, r.w}, zero extended
         // margin of the exit-point test, as 0.5 - VRT_MARGIN * (|pos| + |origin| + 1) = thr0 - VRT_MARGIN * |pos|
@@ -539,11 +543,12 @@ struct CellRay {
             // ---- phase A: cross an empty box that holds the current voxel: the column-top block of the
             // voxel's level (also inside a non-empty cell, above its solid voxels) or the octant cube
             int fwx, fwy, fwz;  // last anchor of the box on each axis
-            const int lvl = (int)(e >> 12) - 1;
+            // the entry's block is 2^L x 2^L cell columns, L + 1 = e >> 12: twice its side in cells against the cube's
+            const int two = 1 << (e >> 12);
             if (FOLD > 0 && !boxed) {
                 fwx = wx; fwy = wy; fwz = wz;  // the voxel itself
-            } else if (e != 0 && (2 << lvl) > d) {  // (measured: better than (1 << lvl) > d and (4 << lvl) > d)
-                const int m4 = (4 << lvl) - 1;
+            } else if (e != 0 && two > d) {  // (measured: better than half and than twice that)
+                const int m4 = 2 * two - 1;  // voxels across the block, less one
                 // texel of the current anchor up to a multiple of n, which is a multiple of the block width
                 const int ux = (wx ^ smx) + P.off[0], uz = (wz ^ smz) + P.off[2];
                 fwx = m4 >= n - 1 ? whix : min(wx + (~(ux ^ smx) & m4), whix);
@@ -555,37 +560,54 @@ struct CellRay {
                 fwy = min((wy | 3) + r4, whiy);
                 fwz = min((wz | 3) + r4, whiz);
             }
-            const float tx = ((float)(fwx + lnx + 1) - rnx) * inx;
-            const float ty = ((float)(fwy + lny + 1) - rny) * iny;
-            const float tz = ((float)(fwz + lnz + 1) - rnz) * inz;
-            k = argmin3(tx, ty, tz);
-            const float tk = k == 0 ? tx : (k == 1 ? ty : tz);
+            // plane parameters of the box's far faces (ln1 = ln + 1: the plane behind anchor fw)
+            const float tx = ((float)(fwx + ln1x) - rnx) * inx;
+            const float ty = ((float)(fwy + ln1y) - rny) * iny;
+            const float tz = ((float)(fwz + ln1z) - rnz) * inz;
+            // util.glsl:28-42 on finite values (an ordinary ray's, or +inf on a frozen axis): y wins over x only when
+            // smaller, z over both only when smaller; the winner's value is the minimum
+            const float txy = __builtin_fminf(tx, ty);
+            const bool  cy = ty < tx, cz = tz < txy;
+            const float tk = __builtin_fminf(txy, tz);
+            k = cz ? 2 : (cy ? 1 : 0);
+            const bool kx = !cy && !cz, ky = cy && !cz;
             // anchors at the exit from the exit point, where it is clear of every plane.  The point is
             // off by at most 2^-24 * (3|i - ro| + |rd t| + |pos|) < 2^-21 * (|pos| + |ro| + 1); a plane
             // within twice that is settled by comparing plane parameters instead (see traverse_skip).
+            // (near: distance of the position's fraction from 0.5, plus the margin's share of |pos|, reaches
+            // thr0 = 0.5 - margin * (|ro| + 1); a fraction that rounds to 1 counts as near either way)
             const float psx = rnx + dnx * tk, psy = rny + dny * tk, psz = rnz + dnz * tk;
-            const float flx = floorf(psx), fly = floorf(psy), flz = floorf(psz);
-            int vx = f2i_small(flx) - lnx, vy = f2i_small(fly) - lny, vz = f2i_small(flz) - lnz;
-            const bool nearx = fabsf((psx - flx) - 0.5f) >= __builtin_fmaf(fabsf(psx), -VRT_MARGIN, thr0x);
-            const bool neary = fabsf((psy - fly) - 0.5f) >= __builtin_fmaf(fabsf(psy), -VRT_MARGIN, thr0y);
-            const bool nearz = fabsf((psz - flz) - 0.5f) >= __builtin_fmaf(fabsf(psz), -VRT_MARGIN, thr0z);
+            const int vx = f2i_floor(psx) - lnx, vy = f2i_floor(psy) - lny, vz = f2i_floor(psz) - lnz;
+            // (not on the exit axis: there the point lies on its plane by construction, and the anchor is known)
+            const bool mx = fma_abs(psx, VRT_MARGIN, __builtin_amdgcn_fractf(psx) - 0.5f) >= thr0x;
+            const bool my = fma_abs(psy, VRT_MARGIN, __builtin_amdgcn_fractf(psy) - 0.5f) >= thr0y;
+            const bool mz = fma_abs(psz, VRT_MARGIN, __builtin_amdgcn_fractf(psz) - 0.5f) >= thr0z;
+            const bool nearx = ((int)mx & (int)!kx) != 0, neary = ((int)my & (int)!ky) != 0, nearz = ((int)mz & (int)!cz) != 0;
 #ifdef VRT_DIAG_SEC_UTIL
             dNear += (nearx || neary || nearz) ? 1u : 0u;
             dNearX += __any((nearx || neary || nearz) ? 1 : 0) ? 1u : 0u;
 #endif
+            // The exit axis lands one past the box: its computed anchor is the box's last or the one behind it (the
+            // exit point lies on that plane up to rounding), so the clamp yields the last and the step is a carry --
+            // added here, next to the comparisons it comes from, where it costs no instruction of its own.
+            const int ox = wx, oy = wy, oz = wz;
+            wx = min(max(vx, ox), fwx) + (kx ? 1 : 0);
+            wy = min(max(vy, oy), fwy) + (ky ? 1 : 0);
+            wz = min(max(vz, oz), fwz) + (cz ? 1 : 0);
             if (__any((nearx || neary || nearz) ? 1 : 0)) {
+                // a plane within the margin: has the reference crossed it before the exit event?  Axis j's events
+                // sort before the exit event of axis k on ties iff j < k.
                 const float i0x = rintf(psx), i0y = rintf(psy), i0z = rintf(psz);
                 const float ttx = (i0x - rnx) * inx, tty = (i0y - rny) * iny, ttz = (i0z - rnz) * inz;
-                const bool  cx = ttx <= tk;
-                const bool  cy = k == 2 ? tty <= tk : tty < tk;
-                const bool  cz = ttz < tk;
-                vx = nearx ? f2i_small(i0x) - lnx - (cx ? 0 : 1) : vx;
-                vy = neary ? f2i_small(i0y) - lny - (cy ? 0 : 1) : vy;
-                vz = nearz ? f2i_small(i0z) - lnz - (cz ? 0 : 1) : vz;
+                const bool  bx = ttx <= tk;
+                const bool  by = cz ? tty <= tk : tty < tk;
+                const bool  bz = ttz < tk;
+                const int sx = f2i_small(i0x) - lnx - (bx ? 0 : 1), sy = f2i_small(i0y) - lny - (by ? 0 : 1),
+                          sz = f2i_small(i0z) - lnz - (bz ? 0 : 1);
+                wx = nearx ? min(max(sx, ox), fwx) : wx;
+                wy = neary ? min(max(sy, oy), fwy) : wy;
+                wz = nearz ? min(max(sz, oz), fwz) : wz;
             }
-            wx = k == 0 ? fwx + 1 : min(max(vx, wx), fwx);
-            wy = k == 1 ? fwy + 1 : min(max(vy, wy), fwy);
-            wz = k == 2 ? fwz + 1 : min(max(vz, wz), fwz);
             // the voxel just entered is tested even when it lies outside the loaded area; the ray
             // ends after that test (raytrace.glsl:52 comes before the next :43).  Only the exit axis can have
             // left the area (the other two stay inside the box), so "some axis beyond its bound" is that test.
@@ -607,16 +629,17 @@ struct CellRay {
 #ifdef VRT_DIAG_SEC_UTIL
                 dB2 += i;
 #endif
-                const float tx = ((float)(wx + lnx + 1) - rnx) * inx;
-                const float ty = ((float)(wy + lny + 1) - rny) * iny;
-                const float tz = ((float)(wz + lnz + 1) - rnz) * inz;
-                const int kk = argmin3(tx, ty, tz);
-                k = kk;
-                const int nx = wx + (kk == 0 ? 1 : 0), ny = wy + (kk == 1 ? 1 : 0), nz = wz + (kk == 2 ? 1 : 0);
+                const float tx = ((float)(wx + ln1x) - rnx) * inx;
+                const float ty = ((float)(wy + ln1y) - rny) * iny;
+                const float tz = ((float)(wz + ln1z) - rnz) * inz;
+                const bool  cy = ty < tx, cz = tz < __builtin_fminf(tx, ty);  // util.glsl:28-42, as in phase A
+                const bool  kx = !cy && !cz, ky = cy && !cz;
+                k = cz ? 2 : (cy ? 1 : 0);
+                const int nx = wx + (kx ? 1 : 0), ny = wy + (ky ? 1 : 0), nz = wz + (cz ? 1 : 0);
                 wx = nx; wy = ny; wz = nz;
-                const int nyz = kk == 1 ? ny : nz, wk = kk == 0 ? nx : nyz;  // (locals: selects, not branches)
+                const int nxy = ky ? ny : nx, wk = cz ? nz : nxy;  // (locals: selects, not branches)
                 if ((wk & 3) == 0) locate(P);
-                else { const int dyz = kk == 1 ? dby : dbz; bit += kk == 0 ? dbx : dyz; e = entry(); }
+                else { const int dxy = ky ? dby : dbx; bit += cz ? dbz : dxy; e = entry(); }
                 if (d == 0 && mask_bit()) { hit = true; live = false; break; }
                 if (((int)(nx > whix) | (int)(ny > whiy) | (int)(nz > whiz)) != 0) { live = false; break; }
                 if (d != 0 || e != 0) break;  // an empty box again: back to phase A

@@ -188,5 +188,5 @@ def test_selftest_library_loads():
     from raytracing_amd import _lib as L
     lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(L.__file__)), "libvrt_selftest.so"))
     for name in ("vrt_selftest_recip", "vrt_selftest_valu_rate", "vrt_selftest_kernarg", "vrt_selftest_normalize",
-                 "vrt_selftest_unorm8"):
+                 "vrt_selftest_unorm8", "vrt_selftest_floor_convert"):
         assert hasattr(lib, name), name

@@ -117,6 +117,17 @@ def test_packed_unorm8_conversion_is_the_canonical_one_for_every_float():
     assert out[0] == 0, f"{out[0]} floats convert differently; first 0x{out[1]:08x}"
 
 
+def test_floor_conversion_instruction_is_floor_then_convert_for_every_float():
+    """f2i_floor (the conversion that rounds toward minus infinity, one instruction) against (int)floorf(x) for every
+    float of magnitude below 2^31."""
+    lib = _selftest_lib()
+    lib.vrt_selftest_floor_convert.restype = C.c_int
+    lib.vrt_selftest_floor_convert.argtypes = [C.c_int, C.POINTER(C.c_ulonglong)]
+    out = (C.c_ulonglong * 2)()
+    assert lib.vrt_selftest_floor_convert(0, out) == 0
+    assert out[0] == 0, f"{out[0]} floats convert differently; first 0x{out[1]:08x}"
+
+
 def test_kernel_argument_segment_starts_with_the_parameter_block():
     """The trace kernels pass their out-of-line code a pointer to the kernel-argument segment in place of a
     copy of TraceParams (vrt_trace.hip: degenerate_pixel, degenerate_primary, degenerate_ray).  That holds

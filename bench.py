@@ -15,13 +15,18 @@ in row order on rank 0 by the library's copy kernel.
 
 Prints ONE JSON line on rank 0.
 
-`roofline` names the roof that binds the kernel of the timed region.  The skip kernel reads 22 MB per
-frame and is bound by vector-instruction issue: `achieved` = wave64 vector instructions per launch (the
-committed counter pass of this command, profiles/traffic.json) / mean HIP-event duration of the kernel
-measured in this run; `peak` = the chip's issue rate for independent v_fma_f32 with eight wavefronts per
-SIMD, measured in this run by libvrt_selftest.so.  `roofline.hbm` is the memory side of the same launch:
-counter bytes (FETCH_SIZE corrected + WRITE_SIZE) / the same duration against the 8 TB/s data-sheet peak.
-`roofline.reference_equivalent_GBs` is the rate at which the REFERENCE's loop would have to move bytes to
+`roofline` names the roof that binds the kernel of the timed region.  The skip kernel moves about 15 MB per
+frame and is bound by vector-instruction issue: `achieved` = wave64 vector instructions per launch (SQ_INSTS_VALU of
+the committed counter passes of this command, profiles/traffic.json -- used only when that record carries the git
+blob hashes of the kernel sources this run was built from, else `valu_count_stale` is true and no fraction is
+printed) / the launch's duration measured in this run; `peak` = the chip's issue rate for the kernels' own mix of
+vector instructions (fma, integer add, compare + select, min/max, conversions) with eight wavefronts per SIMD at
+the clock the chip holds under that load, measured in this run by libvrt_selftest.so; `frac_fma_peak` prices the
+same rate against independent v_fma_f32 (a hotter load: the chip clocks lower under it), `frac_datasheet` against
+1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction.  `roofline.counters` carries the cache hit rates, lanes
+active per vector instruction and wait fractions of the same counter passes.  `roofline.hbm` is the memory side of
+the same launch: counter bytes (FETCH_SIZE corrected + WRITE_SIZE) / the same duration against the 8 TB/s data-sheet
+peak.  `roofline.reference_equivalent_GBs` is the rate at which the REFERENCE's loop would have to move bytes to
 produce the frame in that time (one voxel byte per loop iteration per ray + 4 bytes of BGRA8 per ray); the
 skip kernel does not move those bytes, so this is a speed-up figure, not a bandwidth.
 `roofline_literal` is the literal kernel (one voxel load per reference iteration) on the same frame: the
@@ -47,10 +52,12 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 from raytracing_amd import GraphicsCore, Player, TRACE_AUTO, TRACE_LITERAL, TRACE_SKIP, VOXEL_PACKED_U8, scenes, sharding  # noqa: E402
+from raytracing_amd.kernel_sources import blob_hashes  # noqa: E402
 
 W, H, N_GRID = 1920, 1080, 1024
 STRIP_H = 16
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+VALU_DATASHEET_GINSTR_S = 1024 * 2.4 / 2.0   # 256 CUs x 4 SIMDs, 2.4 GHz, 2 cycles per wave64 v_fma_f32: 1228.8 G/s
 
 
 def rank_pose(rank, world):
@@ -273,8 +280,9 @@ def main():
     overlap = 1 if (multi and strips) else max(1, min(4, args.overlap))
     stream = torch.cuda.ExternalStream(core.stream(), device=torch.device("cuda", local_rank))
     host = args.backend == "gloo"
-    # two frame buffers: the gather of frame k overlaps the trace of frame k+1
-    frames = [torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    # frame buffers: two (the gather of frame k overlaps the trace of frame k+1), and one per stream when more than
+    # two frames are in flight, so that no two launches in flight write one buffer
+    frames = [torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(max(2, overlap))]
     steps_t = torch.zeros((H, W), dtype=torch.int32, device="cuda")
     # pose sharding with N > 1: two buffers of G frames each; the gather of one overlaps the tracing into the other
     G = max(1, args.gather_every)
@@ -350,7 +358,7 @@ def main():
             if fill["n"] == G:
                 flush()
         else:
-            core.trace_device(cam, W, H, 0, H, {"bgra8": frames[b].data_ptr()})
+            core.trace_device(cam, W, H, 0, H, {"bgra8": frames[(counter[0] - 1) % len(frames)].data_ptr()})
 
     def landed(b):
         """Called with the context's stream current: that stream waits for the gather of buffer b, and on rank 0 the
@@ -415,11 +423,24 @@ def main():
     time_every = args.time_every if args.time_every or overlap == 1 else 8   # overlapped launches: their durations in the region too
     core.kernel_time_sampling(max(0, min(time_every, args.steps)))
     core.kernel_time_reset()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
+
+    def timed_region():
+        """EXACTLY --steps steps between two fences (stream waits, and a barrier with more than one rank)."""
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        return time.perf_counter() - t0
+
+    # A region of a few milliseconds is at the mercy of one slow wake-up from its closing wait: such a run times the
+    # region three times (each one the same --steps steps between the same fences) and reports the median, with all
+    # three in `region_ms`.  The decision is taken on the first region's time and agreed between the ranks.
+    regions = [timed_region()]
+    again = torch.tensor([1.0 if regions[0] < 20e-3 else 0.0], dtype=torch.float64, device="cpu" if host else "cuda")
+    if multi:
+        dist.all_reduce(again, op=dist.ReduceOp.MAX)
+    if again.item() > 0:
+        regions += [timed_region(), timed_region()]
     region_ms, region_launches = core.kernel_time()
 
     # the kernel alone: the same launch again, one at a time, every one bracketed by two HIP events on the context's stream
@@ -437,10 +458,11 @@ def main():
     core.kernel_time_sampling(0)
 
     kern_max_s = kern_ms / 1e3 / max(launches, 1)
-    if multi:
-        t = torch.tensor([dt, kern_max_s], dtype=torch.float64, device="cpu" if host else "cuda")
+    if multi:   # every region's time is the slowest rank's
+        t = torch.tensor(regions + [kern_max_s], dtype=torch.float64, device="cpu" if host else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, kern_max_s = float(t[0].item()), float(t[1].item())
+        regions, kern_max_s = [float(v) for v in t[:-1].tolist()], float(t[-1].item())
+    dt = sorted(regions)[len(regions) // 2]
 
     gather_ok = None
     if rank == 0 and multi and not strips:
@@ -461,18 +483,22 @@ def main():
         kern_s = kern_ms / 1e3 / max(launches, 1)
         name = core.last_kernel_name()
         ref_equiv_gbs = alg_bytes / kern_s / 1e9
-        traffic = valu = valu_alone = None
+        # the committed counter record of this command, if it was measured on the kernel sources of this tree
+        traffic = valu = valu_alone = counters = None
+        stale = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf) and not strips:   # the committed counters describe whole-frame launches
+        if os.path.exists(tf) and not strips:   # the counters describe whole-frame launches
             try:
                 prof = json.load(open(tf))
-                traffic = prof.get(name)
-                valu = prof.get(name + "_valu_instructions")
-                if overlap > 1:   # overlapped launches run their rows in plain order, without the bookkeeping of the measured one
-                    valu = prof.get(name + "_plain_order_valu_instructions", valu)
+                stale = prof.get("kernel_sources") != blob_hashes()
+                if not stale:
+                    key = name + "_plain_order" if overlap > 1 and (name + "_plain_order") in prof else name
+                    traffic = prof.get(key)
+                    valu = prof.get(key + "_valu_instructions")
                     valu_alone = prof.get(name + "_valu_instructions")
+                    counters = prof.get(key + "_counters")
             except Exception:
-                traffic = valu = None
+                traffic = valu = valu_alone = counters = None
         hbm = {"achieved": traffic / kern_s / 1e9 if traffic else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                "frac": traffic / kern_s / 1e9 / HBM_PEAK_GBS if traffic else None,
                "bytes": "FETCH_SIZE x 2 (gfx950 tallies 128-B fills as 64 B) + WRITE_SIZE per launch, profiles/traffic.json"}
@@ -492,17 +518,29 @@ def main():
             # one launch at a time: instructions of a launch / its duration.  Overlapped launches share the GPU, so a
             # launch's own duration says little; the rate is then instructions of a launch / the region's time per launch
             per_launch_s = kern_s if overlap == 1 else dt / args.steps
+            achieved = valu / per_launch_s / 1e9 if valu else None
+            alone = (valu_alone or valu) / kern_s / 1e9 if valu else None
+            mix, fma = issue["trace_mix_8_waves"]["ginstr_s"], issue["fma_8_waves"]["ginstr_s"]
             roofline = {"bound": "valu_issue",
-                        "achieved": valu / per_launch_s / 1e9 if valu else None, "peak": issue["fma_8_waves"]["ginstr_s"],
-                        "unit": "G wave64 vector instructions/s",
-                        "frac": valu / per_launch_s / 1e9 / issue["fma_8_waves"]["ginstr_s"] if valu else None,
+                        "achieved": achieved, "peak": mix, "unit": "G wave64 vector instructions/s",
+                        "frac": achieved / mix if valu else None,
+                        "peak_how": "issue rate of the trace kernels' own instruction mix (fma, integer add, compare + select, min/max, "
+                                    "float->int, floor, xor; eight wavefronts per SIMD, every SIMD of the chip) at the clock the chip holds "
+                                    "under it, measured in this run (peak_measured.trace_mix_8_waves)",
+                        "frac_fma_peak": achieved / fma if valu else None,
+                        "frac_datasheet": achieved / VALU_DATASHEET_GINSTR_S if valu else None,
+                        "datasheet_peak": VALU_DATASHEET_GINSTR_S,
                         "achieved_how": ("instructions of a launch / mean duration of a launch (kernel_ms)" if overlap == 1 else
                                          f"instructions of a launch / time per launch over the timed region (ms_per_step): {overlap} "
                                          "streams keep launches overlapping, a launch alone takes kernel_ms, in the region "
                                          "region_sampled_kernel_ms"),
-                        "frac_one_launch_alone": (valu_alone or valu) / kern_s / 1e9 / issue["fma_8_waves"]["ginstr_s"] if valu else None,
+                        "frac_one_launch_alone": alone / mix if valu else None,
+                        "frac_one_launch_alone_datasheet": alone / VALU_DATASHEET_GINSTR_S if valu else None,
                         "valu_instructions_per_launch": valu,
-                        "valu_count_from": "SQ_INSTS_VALU per launch, rocprofv3 --pmc pass of this command (profiles/traffic.json)",
+                        "valu_count_stale": stale,
+                        "valu_count_from": "SQ_INSTS_VALU per launch, rocprofv3 --pmc pass of this command (profiles/traffic.json), taken only "
+                                           "when the record's kernel-source hashes are those of this tree",
+                        "counters": counters,
                         "peak_measured": issue, "hbm": hbm, **common}
         copy_gbs = copy_bandwidth_gbs()
         roofline["measured_copy_GBs"] = copy_gbs
@@ -514,6 +552,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            "region_ms": [r * 1e3 for r in regions],   # every timed region (each: --steps steps between two fences); value and ms_per_step are the median's
             # the same job without the framebuffer gather: every rank's frame / the slowest rank's kernel
             "value_without_gather": rays / args.steps / kern_max_s / 1e6,
             "higher_is_better": True,
@@ -539,7 +578,8 @@ def main():
             import hashlib
             fx = json.load(open(gold))
             if np.array_equal(np.asarray(fx["cam_col_major_bits"], np.uint32), np.asarray(cam, np.float32).view(np.uint32)):
-                last = (batch[fill["last"][0]][fill["last"][1]] if batch is not None else frames[(counter[0] - 1) & 1]).cpu().numpy()
+                last_frame = frames[(counter[0] - 1) & 1] if strips else frames[(counter[0] - 1) % len(frames)]
+                last = (batch[fill["last"][0]][fill["last"][1]] if batch is not None else last_frame).cpu().numpy()
                 line["parity"] = {"bgra8_sha256_equals_oracle_golden": hashlib.sha256(last.tobytes()).hexdigest() == fx["sha256"]["bgra8"],
                                   "steps_sum_equals_oracle_golden": sum_steps == fx["totals"]["steps"] if not strips else None}
         if world == 1 and not args.no_cpu_baseline:

@@ -576,7 +576,9 @@ struct CellRay {
             // within twice that is settled by comparing plane parameters instead (see traverse_skip).
             // (near: distance of the position's fraction from 0.5, plus the margin's share of |pos|, reaches
             // thr0 = 0.5 - margin * (|ro| + 1); a fraction that rounds to 1 counts as near either way)
-            const float psx = rnx + dnx * tk, psy = rny + dny * tk, psz = rnz + dnz * tk;
+            // (fused: this point is the kernel's own, not a value of the reference's; one rounding instead of two keeps it
+            // inside the error bound above)
+            const float psx = __builtin_fmaf(dnx, tk, rnx), psy = __builtin_fmaf(dny, tk, rny), psz = __builtin_fmaf(dnz, tk, rnz);
             const int vx = f2i_floor(psx) - lnx, vy = f2i_floor(psy) - lny, vz = f2i_floor(psz) - lnz;
             // (not on the exit axis: there the point lies on its plane by construction, and the anchor is known)
             const bool mx = fma_abs(psx, VRT_MARGIN, __builtin_amdgcn_fractf(psx) - 0.5f) >= thr0x;
@@ -594,7 +596,7 @@ struct CellRay {
             wx = min(max(vx, ox), fwx) + (kx ? 1 : 0);
             wy = min(max(vy, oy), fwy) + (ky ? 1 : 0);
             wz = min(max(vz, oz), fwz) + (cz ? 1 : 0);
-            if (__any((nearx || neary || nearz) ? 1 : 0)) {
+            if (((int)nearx | (int)neary | (int)nearz) != 0) {  // (skipped by the wavefront when no lane is near)
                 // a plane within the margin: has the reference crossed it before the exit event?  Axis j's events
                 // sort before the exit event of axis k on ties iff j < k.
                 const float i0x = rintf(psx), i0y = rintf(psy), i0z = rintf(psz);

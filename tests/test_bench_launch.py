@@ -65,11 +65,26 @@ def test_single_rank_over_rccl_gathers_packed_pixels():
 
 
 def test_counter_record_the_bench_prices_is_complete():
-    """bench.py takes the kernel's bytes and instruction counts per launch from profiles/traffic.json (a committed
-    counter pass): both launch modes must be there, and the figures must hang together."""
+    """bench.py takes the kernel's bytes, instruction counts and counters per launch from profiles/traffic.json (committed
+    counter passes of its own command): both launch modes must be there, and the figures must hang together."""
     t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-    for key in ("skip", "skip_valu_instructions", "skip_salu_instructions", "skip_plain_order_valu_instructions"):
-        assert isinstance(t[key], int) and t[key] > 0, key
-    assert t["skip"] == t["_detail"]["fetch_bytes_corrected"] + t["_detail"]["write_bytes"]
-    assert t["_detail"]["write_bytes"] >= 1920 * 1080 * 4             # at least the frame is written
+    for key in ("skip", "skip_valu_instructions", "skip_salu_instructions", "skip_plain_order", "skip_plain_order_valu_instructions"):
+        assert isinstance(t[key], (int, float)) and t[key] > 0, key
+    for mode in ("skip_counters", "skip_plain_order_counters"):
+        c = t[mode]
+        assert abs(t[mode[:-len("_counters")]] - (c["fetch_bytes"] + c["write_bytes"])) < 1
+        assert c["write_bytes"] >= 1920 * 1080 * 4             # at least the frame is written
+        assert 0.5 < c["lanes_active_per_vector_instruction"] <= 1.0
+        assert 0.0 < c["l1_hit_rate"] <= 1.0 and 0.0 < c["l2_hit_rate"] <= 1.0
+        assert 0.0 < c["issue_wait_fraction_of_wave_cycles"] < 1.0 and 0.0 < c["memory_wait_fraction_of_wave_cycles"] < 1.0
+        assert c["waves"] == 32640
     assert 0.9 < t["skip_plain_order_valu_instructions"] / t["skip_valu_instructions"] < 1.0
+
+
+def test_counter_record_was_measured_on_the_kernel_sources_of_this_tree():
+    """The record carries the git blob hashes of the files the kernel was compiled from when it was measured; bench.py
+    prices a run with it only when they match the tree's (else it prints valu_count_stale and no fraction).  A change
+    to the kernels without a fresh counter pass fails here."""
+    from raytracing_amd.kernel_sources import blob_hashes
+    t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    assert t["kernel_sources"] == blob_hashes(), "run tools/profile_r03.sh on the GPU box and copy its traffic.json to profiles/"

@@ -508,6 +508,19 @@ struct CellRay {
         if (live) locate(P);  // the anchor's cell (the start voxel itself is never tested)
     }
 
+#ifdef VRT_DIAG_STAGE
+    // instruction-budget builds (tools/stage_budget.sh): a word that depends on everything begin() worked out
+    VRT_DEV unsigned digest() const
+    {
+        return __float_as_uint(rnx) ^ __float_as_uint(rny) ^ __float_as_uint(rnz) ^ __float_as_uint(dnx) ^ __float_as_uint(dny) ^
+               __float_as_uint(dnz) ^ __float_as_uint(inx) ^ __float_as_uint(iny) ^ __float_as_uint(inz) ^ __float_as_uint(thr0x) ^
+               __float_as_uint(thr0y) ^ __float_as_uint(thr0z) ^ (unsigned)lnx ^ (unsigned)lny ^ (unsigned)lnz ^ (unsigned)smx ^
+               ((unsigned)smy << 1) ^ ((unsigned)smz << 2) ^ dsel ^ (unsigned)wx ^ ((unsigned)wy << 8) ^ ((unsigned)wz << 16) ^
+               (unsigned)w0 ^ (unsigned)d ^ (unsigned)bit ^ pyr_lo ^ pyr_hi ^ e ^ (unsigned)cur_mask ^ (unsigned)(cur_mask >> 32) ^
+               (live ? 1u : 0u);
+    }
+#endif
+
     // a ray that ended elsewhere: the loop has nothing to do for this lane
     VRT_DEV void idle() { live = false; hit = false; work = 0; iters = 0; wx = wy = wz = w0 = 0; d = 0; e = 0; }
 
@@ -705,7 +718,13 @@ VRT_DEV void traverse_cells_regular(const TraceParams &P, float rox, float roy, 
     if (CAMERA) ray.template begin<false, true>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, P.a0[0], P.a0[1], P.a0[2], 0u);
     else ray.template begin<false>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, f2i_small(floorf(rox)),
                                    f2i_small(floorf(roy)), f2i_small(floorf(roz)), 0u);
+#if defined(VRT_DIAG_STAGE) && VRT_DIAG_STAGE == 2
+    H.steps = ray.digest(); return;  // (instruction-budget build: stops after the set-up)
+#endif
     while (ray.live) ray.template trip<PRIMARY_FOLD>(P);
+#if defined(VRT_DIAG_STAGE) && VRT_DIAG_STAGE == 3
+    H.steps = ray.steps_done() ^ (unsigned)ray.k ^ (ray.hit ? 4u : 0u); return;  // (... after the trips)
+#endif
     ray.finish(P, rox, roy, roz, lox, loy, loz, H);
 }
 
@@ -1072,6 +1091,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         bool  regular = true;  // (the capped form sorts its rays out itself)
         if (FORM == FORM_CAPPED) raygen(P, col, P.h - row, rdx, rdy, rdz);
         else regular = raygen_regular(P, col, P.h - row, rdx, rdy, rdz);
+#if defined(VRT_DIAG_STAGE) && VRT_DIAG_STAGE == 1
+        // instruction-budget build: the kernel stops after ray generation (one word per pixel keeps it alive)
+        ((unsigned *)P.bgra8)[(size_t)q * P.w + col] = __float_as_uint(rdx) ^ __float_as_uint(rdy) ^ __float_as_uint(rdz) ^ (regular ? 1u : 0u);
+        return;
+#endif
         const float rox = P.m[12], roy = P.m[13], roz = P.m[14];
         // loaded area (raytrace.glsl:19-24), evaluated once per frame on the host
         const int lox = P.lo[0], loy = P.lo[1], loz = P.lo[2], upx = P.up[0], upy = P.up[1], upz = P.up[2];
@@ -1081,6 +1105,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             else traverse_cells_regular<T, FORM == FORM_POW2, true>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, H);
             work = H.work;
         }
+#if defined(VRT_DIAG_STAGE) && VRT_DIAG_STAGE >= 2
+        // instruction-budget builds: stop after the set-up (2), the trips (3), the ray's outputs (4)
+        ((unsigned *)P.bgra8)[(size_t)q * P.w + col] =
+            VRT_DIAG_STAGE == 4 ? H.steps ^ __float_as_uint(H.t) ^ __float_as_uint(H.hx) ^ __float_as_uint(H.hy) ^ __float_as_uint(H.hz) ^
+                                      H.block_id ^ (unsigned)H.k ^ (unsigned)H.sk ^ (unsigned)H.vx ^ (unsigned)H.vy ^ (unsigned)H.vz
+                                : H.steps;
+        return;
+#endif
         // What follows the traversal loop takes nothing over from before it but the ray's result: the pixel's
         // coordinates are worked out again from the thread index, and the launch parameters are read again
         // from the kernel-argument segment.  The loop has no register to spare at 64 per lane (kept across it,

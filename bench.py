@@ -206,7 +206,7 @@ def main():
                          "to one gather, which overlaps the tracing of the next buffer; every frame still reaches rank 0 "
                          "inside the timed region.  1 = one gather per frame")
     ap.add_argument("--gather-pixels", choices=["bgr", "bgra"], default="bgr",
-                    help="what crosses the links of a pose-sharded gather: bgr = three bytes per pixel (the alpha byte, 255 on "
+                    help="what crosses the links of a gather (pose- or strip-sharded): bgr = three bytes per pixel (the alpha byte, 255 on "
                          "every path of the shader, is dropped by a pack kernel before the send and restored on rank 0 after "
                          "it); bgra = the frames as they are")
     ap.add_argument("--overlap", type=int, default=2,
@@ -303,7 +303,9 @@ def main():
     if strips:
         pad_rows = sharding.max_strip_rows(H, STRIP_H, world)
         packed = [torch.zeros((pad_rows, W, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
-        parts_buf = [torch.zeros((world, pad_rows, W, 4), dtype=torch.uint8, device="cuda") if rank == 0 else None
+        # what crosses the links: the packed rows, without their alpha byte unless --gather-pixels bgra
+        packed3 = [torch.zeros((pad_rows, W, 3), dtype=torch.uint8, device="cuda") for _ in range(2)] if bgr else None
+        parts_buf = [torch.zeros((world, pad_rows, W, C_SENT), dtype=torch.uint8, device="cuda") if rank == 0 else None
                      for _ in range(2)]
     pending = [None, None]
     torch.cuda.synchronize()
@@ -327,26 +329,32 @@ def main():
         counter[0] += 1
         if strips and host:
             core.trace_strips_device(cam, W, H, STRIP_H, rank, world, {"bgra8": packed[b].data_ptr()})
+            send = packed[b]
+            if bgr:
+                core.pack_bgr(packed[b].data_ptr(), packed3[b].data_ptr(), pad_rows * W)
+                send = packed3[b]
             core.sync()
-            cpu_parts = [torch.empty((pad_rows, W, 4), dtype=torch.uint8) for _ in range(world)] if rank == 0 else None
-            dist.gather(packed[b].cpu(), cpu_parts, dst=0)
+            cpu_parts = [torch.empty((pad_rows, W, C_SENT), dtype=torch.uint8) for _ in range(world)] if rank == 0 else None
+            dist.gather(send.cpu(), cpu_parts, dst=0)
             if rank == 0:
                 parts_buf[b].copy_(torch.stack(cpu_parts))
                 torch.cuda.synchronize()
-                core.assemble_strips(parts_buf[b].data_ptr(), frames[b].data_ptr(), W * 4, H, STRIP_H, world, pad_rows)
+                assemble(b)
         elif strips:
             with torch.cuda.stream(stream):
                 if pending[b] is not None:
                     pending[b].wait()
                 core.trace_strips_device(cam, W, H, STRIP_H, rank, world, {"bgra8": packed[b].data_ptr()})
                 if multi:
-                    pending[b] = dist.gather(packed[b], list(parts_buf[b].unbind(0)) if rank == 0 else None, dst=0,
-                                             async_op=True)
+                    send = packed[b]
+                    if bgr:   # the pack kernel runs on the context's stream, behind the trace
+                        core.pack_bgr(packed[b].data_ptr(), packed3[b].data_ptr(), pad_rows * W)
+                        send = packed3[b]
+                    pending[b] = dist.gather(send, list(parts_buf[b].unbind(0)) if rank == 0 else None, dst=0, async_op=True)
                     if rank == 0:
                         pending[b].wait()            # orders the copy below behind the gather on this stream
                         pending[b] = None
-                        core.assemble_strips(parts_buf[b].data_ptr(), frames[b].data_ptr(), W * 4, H, STRIP_H, world,
-                                             pad_rows)
+                        assemble(b)
         elif multi:
             b, j = fill["buf"], fill["n"]
             with torch.cuda.stream(stream):
@@ -359,6 +367,14 @@ def main():
                 flush()
         else:
             core.trace_device(cam, W, H, 0, H, {"bgra8": frames[(counter[0] - 1) % len(frames)].data_ptr()})
+
+    def assemble(b):
+        """Rank 0, strips: the gathered parts of buffer b back in image order (and, if they travelled without it, with
+        their alpha byte again), one launch on the context's stream."""
+        if bgr:
+            core.assemble_strips_bgr(parts_buf[b].data_ptr(), frames[b].data_ptr(), W, H, STRIP_H, world, pad_rows)
+        else:
+            core.assemble_strips(parts_buf[b].data_ptr(), frames[b].data_ptr(), W * 4, H, STRIP_H, world, pad_rows)
 
     def landed(b):
         """Called with the context's stream current: that stream waits for the gather of buffer b, and on rank 0 the
@@ -563,7 +579,7 @@ def main():
             "frames_in_flight": overlap,
             "config": {"workload": "1920x1080 primary rays over 1024^3 u8 procedural terrain (pose B at y=40.3), "
                                    + ("world replicated per GPU, ONE frame dealt in interleaved 16-row strips, "
-                                      "BGRA8 gather + row reorder on rank 0" if strips else
+                                      "gather (three bytes per pixel) + row reorder on rank 0" if strips else
                                       "world replicated per GPU, one pose per GPU, BGRA8 gather to rank 0"
                                       + (f" ({G} frames per gather)" if multi else "")),
                        "kernel": name, "grid_n": N_GRID, "width": W, "height": H,
@@ -587,6 +603,8 @@ def main():
         if multi and not strips:
             line["gather"] = {"bytes_per_pixel_on_the_link": C_SENT, "frames_per_gather": G,
                               "last_frame_of_every_rank_equals_its_trace": gather_ok}
+        if multi and strips:
+            line["gather"] = {"bytes_per_pixel_on_the_link": C_SENT, "bytes_per_frame_on_the_links": (world - 1) * pad_rows * W * C_SENT}
         print(json.dumps(line), flush=True)
 
     if strips and multi and rank == 0:

@@ -133,9 +133,13 @@ int vrt_trace(vrt_ctx *ctx, const float cam_col_major[16], uint32_t w, uint32_t 
  * and the traversal index must be current -- call vrt_reset_distance_field (or vrt_trace once) after the last
  * change to the world, else VRT_E_UNSUPPORTED.  Anything beyond these limits is VRT_E_INVALID_ARG with a message.
  * Every context on one GPU shares that GPU's array, which keeps the last call's tables and measurements (the
- * library refills and re-tags what a call needs): calls that overlap on one GPU -- two streams, two threads --
- * race on it; calls on one stream, or separated by vrt_sync, do not.  No HIP events are recorded (vrt_kernel_time
- * does not see these launches).  The call only enqueues work on the context's stream. */
+ * library refills and re-tags what a call needs): launches that overlap on one GPU -- two streams, two threads --
+ * would race on it, so the library keeps them apart: a call that arrives while another thread is inside
+ * vrt_trace_static on the same GPU returns VRT_E_UNSUPPORTED (nothing enqueued), and a call on another stream than the
+ * last one first makes its stream wait for that launch (one event per GPU, created by vrt_create; calls that stay on
+ * one stream wait for nothing).  vrt_create and vrt_trace_static may be called from several threads; a context itself
+ * is still driven by one thread at a time.  No timing events are recorded (vrt_kernel_time does not see these
+ * launches).  The call only enqueues work on the context's stream. */
 int vrt_trace_static(vrt_ctx *ctx, const float cam_col_major[16], uint32_t w, uint32_t h,
                      uint32_t y0, uint32_t y1, const vrt_outputs *out);
 
@@ -171,6 +175,13 @@ uint32_t vrt_strip_rows(uint32_t h, uint32_t strip_h, uint32_t part, uint32_t pa
 int vrt_assemble_strips(vrt_ctx *ctx, const void *gathered, void *frame, uint32_t row_bytes, uint32_t h,
                         uint32_t strip_h, uint32_t parts, uint32_t part_stride_rows);
 
+/* vrt_assemble_strips for parts that travelled without their alpha byte (vrt_pack_bgr): `gathered_bgr` holds BGR8 rows of
+ * 3 * w bytes, laid out as above; `frame_bgra` receives the h rows as BGRA8, alpha 255 (render.comp:9-13 stores a = 1) --
+ * the reorder and the fourth byte in one pass.  w a multiple of 4; the parts 4-byte, the frame 16-byte aligned; DEVICE
+ * memory, not overlapping; enqueued on the context's stream.  No counterpart in the reference (one device). */
+int vrt_assemble_strips_bgr(vrt_ctx *ctx, const void *gathered_bgr, void *frame_bgra, uint32_t w, uint32_t h,
+                            uint32_t strip_h, uint32_t parts, uint32_t part_stride_rows);
+
 /* ---- several GPUs driven by ONE process: the framebuffer exchange ------------------------------------------
  * The reference picks one physical device (src/graphics/mod.rs:325-342) and has no counterpart.  A host that
  * shards a frame (vrt_trace_strips) or a batch of poses over n GPUs creates one context per HIP device, each
@@ -182,7 +193,11 @@ int vrt_assemble_strips(vrt_ctx *ctx, const void *gathered, void *frame, uint32_
  * the context they belong to.  (A host with one process per GPU gathers with its own collective and calls
  * vrt_assemble_strips.) */
 typedef struct vrt_comm vrt_comm;
-int vrt_comm_create(vrt_ctx *const *ctxs, uint32_t n, vrt_comm **out);  /* n = 1..64 contexts on distinct devices */
+/* n = 1..64 contexts on distinct devices.  With VRT_COMM_ALLOW_SHARED_DEVICE=1 in the environment (a rehearsal switch:
+ * the n-context control flow -- offsets, strides, joins, stream order -- on a machine with fewer GPUs) contexts may share
+ * the root's device; their parts are copied on that device between two events instead of travelling through RCCL.
+ * More than one context per process has only been run that way: no machine with two GPUs was available to the build. */
+int vrt_comm_create(vrt_ctx *const *ctxs, uint32_t n, vrt_comm **out);
 int vrt_comm_destroy(vrt_comm *comm);                                   /* waits for the contexts' streams */
 uint32_t vrt_comm_size(const vrt_comm *comm);
 /* bytes_each bytes at send[i] (context i's device) -> recv_root + i * bytes_each (root's device): whole frames of
@@ -194,6 +209,13 @@ int vrt_gather(vrt_comm *comm, const void *const *send, size_t bytes_each, void 
  * rows, root's device) as vrt_assemble_strips does. */
 int vrt_gather_strips(vrt_comm *comm, const void *const *packed, void *gathered, void *frame, uint32_t row_bytes,
                       uint32_t h, uint32_t strip_h, uint32_t part_stride_rows);
+/* The same for a BGRA8 frame with three bytes per pixel on the links (a quarter less through the root's links, which
+ * bound the step: 24.9 instead of 33.2 MB for a 3840 x 2160 frame): context i packs its rows packed_bgra[i] into its own
+ * buffer packed_bgr[i] (3 * w bytes per row, vrt_pack_bgr on its stream), the BGR8 parts are gathered into
+ * `gathered_bgr` (n * part_stride_rows rows of 3 * w bytes, root's device) and vrt_assemble_strips_bgr writes
+ * `frame_bgra`.  w a multiple of 4. */
+int vrt_gather_strips_bgr(vrt_comm *comm, const void *const *packed_bgra, void *const *packed_bgr, void *gathered_bgr,
+                          void *frame_bgra, uint32_t w, uint32_t h, uint32_t strip_h, uint32_t part_stride_rows);
 
 /* The frame as it travels between GPUs: B, G, R of every pixel without the alpha byte, which is 255 on every path
  * of the shader (render.comp:9-13), so three quarters of the bytes cross the link that bounds a gathered frame.

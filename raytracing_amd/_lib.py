@@ -64,6 +64,7 @@ SYMBOLS = {
     "vrt_strip_rows": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "vrt_assemble_strips": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                       C.c_uint32]),
+    "vrt_assemble_strips_bgr": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "vrt_pack_bgr": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_size_t]),
     "vrt_unpack_bgra": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_size_t]),
     "vrt_alloc_host": (C.c_int, [_CTX, C.c_size_t, C.POINTER(C.c_void_p)]),
@@ -86,6 +87,8 @@ SYMBOLS = {
     "vrt_gather": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.c_void_p]),
     "vrt_gather_strips": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                     C.c_uint32, C.c_uint32]),
+    "vrt_gather_strips_bgr": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p,
+                                        C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "vrt_last_error": (C.c_char_p, []),
     "vrt_version": (C.c_char_p, []),
 }

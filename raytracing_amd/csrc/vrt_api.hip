@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <new>
 #include <vector>
 
@@ -82,31 +83,45 @@ constexpr size_t   kStaticScratchBytes = kStaticSchedOffset + kStaticSchedBytes;
 static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
 
 constexpr int kMaxDevices = 64;
+// What guards a GPU's one static scratch.  Host side: `in_use` is held for the length of a vrt_trace_static call, which
+// reads and updates the host's notes on the scratch (tables filled for, dispatch-order generation): a second thread
+// that calls meanwhile gets VRT_E_UNSUPPORTED instead of a torn update.  Device side: launches that use the scratch
+// from two streams must not run side by side; `done` is recorded behind every launch and a call that arrives on another
+// stream than the last one makes its stream wait for it (calls that stay on one stream touch no event wait).
 struct StaticScratch {
-    bool    ready = false;
-    Scratch s;
+    std::atomic<bool> ready{false};
+    std::atomic<bool> in_use{false};
+    Scratch     s;
+    hipEvent_t  done = nullptr;          // behind the last launch that used the scratch
+    hipStream_t last_stream = nullptr;   // the stream that launch went to (null: none yet)
 };
-StaticScratch g_static[kMaxDevices];  // one GPU's static calls may not overlap; neither may contexts be created concurrently
+StaticScratch g_static[kMaxDevices];
+std::atomic<bool> g_static_setup{false};  // one thread at a time looks a GPU's scratch up for the first time
 
 // The device's own copy of `scratch`, looked up once per device with that device current.
-int static_scratch_for(int device, Scratch **out)
+int static_scratch_for(int device, StaticScratch **out)
 {
     if (device < 0 || device >= kMaxDevices) return fail(VRT_E_INVALID_ARG, "device %d beyond the %d the static scratch covers", device, kMaxDevices);
     StaticScratch &st = g_static[device];
-    if (!st.ready) {
-        HIP_TRY(hipSetDevice(device));
-        void *ptr = nullptr;
-        HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
-        if (!ptr) return fail(VRT_E_HIP, "hipGetSymbolAddress returned no address for the static scratch");
-        st.s = Scratch{};
-        st.s.tables = static_cast<float *>(ptr);
-        st.s.max_dim = kStaticMaxDim;
-        st.s.sin_cap = kStaticMaxGrid + 8;
-        st.s.sched = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(ptr) + kStaticSchedOffset);
-        st.s.sched_capacity = kStaticSchedCap;
-        st.ready = true;  // the array is zero when the code object is loaded: generation tags start clean
+    if (!st.ready.load(std::memory_order_acquire)) {
+        while (g_static_setup.exchange(true, std::memory_order_acquire)) {}  // (set-up of a few microseconds, once per GPU)
+        struct Release { ~Release() { g_static_setup.store(false, std::memory_order_release); } } release;
+        if (!st.ready.load(std::memory_order_acquire)) {
+            HIP_TRY(hipSetDevice(device));
+            void *ptr = nullptr;
+            HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+            if (!ptr) return fail(VRT_E_HIP, "hipGetSymbolAddress returned no address for the static scratch");
+            if (!st.done) HIP_TRY(hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
+            st.s = Scratch{};
+            st.s.tables = static_cast<float *>(ptr);
+            st.s.max_dim = kStaticMaxDim;
+            st.s.sin_cap = kStaticMaxGrid + 8;
+            st.s.sched = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(ptr) + kStaticSchedOffset);
+            st.s.sched_capacity = kStaticSchedCap;
+            st.ready.store(true, std::memory_order_release);  // the array is zero when the code object is loaded: generation tags start clean
+        }
     }
-    *out = &st.s;
+    *out = &st;
     return VRT_OK;
 }
 
@@ -556,7 +571,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out)
     HIP_TRY(hipSetDevice(cfg->device));
     {   // the static scratch of vrt_trace_static: its address on this device, taken now so that the entry point itself
         // has no set-up left to do
-        Scratch *unused = nullptr;
+        StaticScratch *unused = nullptr;
         int rc = static_scratch_for(cfg->device, &unused);
         if (rc != VRT_OK) return rc;
     }
@@ -731,8 +746,15 @@ int vrt_trace_static(vrt_ctx *c, const float cam[16], uint32_t w, uint32_t h, ui
             return fail(VRT_E_INVALID_ARG, "%llu wavefronts of 64 pixels beyond the static scratch's %u (3840 x 2160 has 129600)",
                         (unsigned long long)waves, kStaticSchedCap);
     }
-    Scratch *S = nullptr;
-    { int rc = static_scratch_for(c->device, &S); if (rc != VRT_OK) return rc; }
+    StaticScratch *st = nullptr;
+    { int rc = static_scratch_for(c->device, &st); if (rc != VRT_OK) return rc; }
+    if (st->in_use.exchange(true, std::memory_order_acquire))
+        return fail(VRT_E_UNSUPPORTED, "the static scratch of device %d is in use: another vrt_trace_static call is running on this GPU",
+                    c->device);
+    struct Release { std::atomic<bool> &f; ~Release() { f.store(false, std::memory_order_release); } } release{st->in_use};
+    Scratch *S = &st->s;
+    // launches from another stream than the last one: behind that one (its tables and slots are this one's too)
+    if (st->last_stream && st->last_stream != c->stream) HIP_TRY(hipStreamWaitEvent(c->stream, st->done, 0));
     vrt::RowMap rows{y0, y1 - y0, 0, 0, 1};
     vrt::TraceParams p;
     bool use_skip = false;
@@ -742,6 +764,8 @@ int vrt_trace_static(vrt_ctx *c, const float cam[16], uint32_t w, uint32_t h, ui
     if (use_skip) { int rc = attach_row_sched(c, *S, p, 1); if (rc != VRT_OK) return rc; }
     if (use_skip) { HIP_TRY(vrt::launch_trace_skip(p, c->voxel_bytes, c->stream)); c->last_kernel = "skip"; }
     else          { HIP_TRY(vrt::launch_trace_literal(p, c->voxel_bytes, c->stream)); c->last_kernel = "literal"; }
+    HIP_TRY(hipEventRecord(st->done, c->stream));
+    st->last_stream = c->stream;
     return VRT_OK;
 }
 
@@ -825,6 +849,26 @@ int vrt_assemble_strips(vrt_ctx *c, const void *gathered, void *frame, uint32_t 
     HIP_TRY(hipSetDevice(c->device));
     { int rc = join_lanes(c); if (rc != VRT_OK) return rc; }
     HIP_TRY(vrt::launch_assemble_strips(gathered, frame, row_bytes, h, strip_h, parts, part_stride_rows, c->stream));
+    return VRT_OK;
+}
+
+int vrt_assemble_strips_bgr(vrt_ctx *c, const void *gathered_bgr, void *frame_bgra, uint32_t w, uint32_t h, uint32_t strip_h,
+                            uint32_t parts, uint32_t part_stride_rows)
+{
+    if (!c || !gathered_bgr || !frame_bgra) return fail(VRT_E_INVALID_ARG, "null argument");
+    if (strip_h == 0 || parts == 0 || w == 0 || h == 0 || h > 16384u || w > 16384u)
+        return fail(VRT_E_INVALID_ARG, "bad strip partition or frame size");
+    if (w % 4u != 0) return fail(VRT_E_INVALID_ARG, "frame width %u is not a multiple of 4 pixels", w);
+    if (((uintptr_t)frame_bgra & 15u) || ((uintptr_t)gathered_bgr & 3u))
+        return fail(VRT_E_INVALID_ARG, "frame must be 16-byte and the gathered parts 4-byte aligned");
+    uint32_t most = 0;
+    for (uint32_t part = 0; part < parts; ++part) most = std::max(most, vrt_strip_rows(h, strip_h, part, parts));
+    if (part_stride_rows < most)
+        return fail(VRT_E_INVALID_ARG, "part_stride_rows %u is less than the %u rows of the largest part", part_stride_rows, most);
+    if (gathered_bgr == frame_bgra) return fail(VRT_E_INVALID_ARG, "gathered and frame must not overlap");
+    HIP_TRY(hipSetDevice(c->device));
+    { int rc = join_lanes(c); if (rc != VRT_OK) return rc; }
+    HIP_TRY(vrt::launch_assemble_strips_bgr(gathered_bgr, frame_bgra, w, h, strip_h, parts, part_stride_rows, c->stream));
     return VRT_OK;
 }
 

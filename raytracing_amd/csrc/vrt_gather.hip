@@ -70,6 +70,37 @@ __global__ __launch_bounds__(256) void k_unpack_bgra(const uint32_t *__restrict_
                          (w1 >> 16) | ((w2 & 0xffu) << 16) | 0xff000000u, (w2 >> 8) | 0xff000000u);
 }
 
+// Gathered strip buffers that travelled as BGR8 -> the BGRA8 frame in image order: the row reorder of
+// k_assemble_strips and the alpha byte of k_unpack_bgra in one pass (3 bytes read, 4 written per pixel; the frame is
+// not read or written a second time).  One lane moves four pixels; a row holds row_quads of them.
+__global__ __launch_bounds__(256) void k_assemble_strips_bgr(const uint32_t *__restrict__ gathered, uint4 *__restrict__ frame,
+                                                             uint32_t row_quads, uint32_t strip_h, uint32_t parts,
+                                                             uint32_t part_stride_rows)
+{
+    const uint32_t r = blockIdx.y;
+    const uint32_t s = r / strip_h;
+    const uint32_t part = s % parts;
+    const uint32_t q = (s / parts) * strip_h + (r - s * strip_h);
+    const uint32_t *src = gathered + ((size_t)part * part_stride_rows + q) * row_quads * 3u;
+    uint4 *dst = frame + (size_t)r * row_quads;
+    for (uint32_t u = blockIdx.x * 256u + threadIdx.x; u < row_quads; u += gridDim.x * 256u) {
+        const uint32_t w0 = src[3u * u], w1 = src[3u * u + 1u], w2 = src[3u * u + 2u];
+        dst[u] = make_uint4((w0 & 0xffffffu) | 0xff000000u, (w0 >> 24) | ((w1 & 0xffffu) << 8) | 0xff000000u,
+                            (w1 >> 16) | ((w2 & 0xffu) << 16) | 0xff000000u, (w2 >> 8) | 0xff000000u);
+    }
+}
+
+hipError_t launch_assemble_strips_bgr(const void *gathered, void *frame, uint32_t w, uint32_t h, uint32_t strip_h,
+                                      uint32_t parts, uint32_t part_stride_rows, hipStream_t s)
+{
+    const uint32_t row_quads = w / 4u;
+    uint32_t gx = (row_quads + 255u) / 256u;
+    if (gx > 64u) gx = 64u;
+    hipLaunchKernelGGL(k_assemble_strips_bgr, dim3(gx, h), dim3(256), 0, s, (const uint32_t *)gathered, (uint4 *)frame, row_quads,
+                       strip_h, parts, part_stride_rows);
+    return hipGetLastError();
+}
+
 hipError_t launch_pack_bgr(const void *bgra, void *bgr, size_t pixels, hipStream_t s)
 {
     const size_t quads = pixels / 4;

@@ -129,6 +129,11 @@ hipError_t launch_any_nonzero_u16(const uint16_t *p, size_t count, uint32_t *fla
 hipError_t launch_assemble_strips(const void *gathered, void *frame, uint32_t row_bytes, uint32_t h,
                                   uint32_t strip_h, uint32_t parts, uint32_t part_stride_rows, hipStream_t s);
 
+// The same from parts that hold BGR8 rows (3 * w bytes each) into a BGRA8 frame; w a multiple of 4, gathered 4-byte and
+// frame 16-byte aligned.
+hipError_t launch_assemble_strips_bgr(const void *gathered, void *frame, uint32_t w, uint32_t h, uint32_t strip_h,
+                                      uint32_t parts, uint32_t part_stride_rows, hipStream_t s);
+
 // BGRA8 <-> BGR8 (alpha dropped / restored as 255); `pixels` a multiple of 4, both buffers 16- / 4-byte aligned
 hipError_t launch_pack_bgr(const void *bgra, void *bgr, size_t pixels, hipStream_t s);
 hipError_t launch_unpack_bgra(const void *bgr, void *bgra, size_t pixels, hipStream_t s);

@@ -244,6 +244,10 @@ class GraphicsCore:
         L.check(L.lib().vrt_assemble_strips(self._ctx, gathered, frame, row_bytes, h, strip_h, parts,
                                             part_stride_rows))
 
+    def assemble_strips_bgr(self, gathered_bgr, frame_bgra, w, h, strip_h, parts, part_stride_rows):
+        """The same for parts that travelled as BGR8 rows (3 * w bytes each): writes the BGRA8 frame, alpha 255."""
+        L.check(L.lib().vrt_assemble_strips_bgr(self._ctx, gathered_bgr, frame_bgra, w, h, strip_h, parts, part_stride_rows))
+
     def pack_bgr(self, bgra_ptr, bgr_ptr, pixels):
         """Enqueue BGRA8 -> BGR8 (device addresses; the frame as it travels between GPUs)."""
         L.check(L.lib().vrt_pack_bgr(self._ctx, bgra_ptr, bgr_ptr, pixels))

@@ -27,7 +27,7 @@ def pose_indices(count, part, parts):
     return list(range(part, count, parts))
 
 
-def gather_frame(packed, h, strip_h, dst=0, group=None, out=None, core=None, pad_rows=None):
+def gather_frame(packed, h, strip_h, dst=0, group=None, out=None, core=None, pad_rows=None, pixels="bgra"):
     """Gather every rank's packed rows (tensor [rows_r, ...]) to `dst` and return the full
     frame [h, ...] there (None elsewhere).  Ranks own different row counts when the strip
     count is not a multiple of the world size, so buffers are padded to the largest.
@@ -37,7 +37,10 @@ def gather_frame(packed, h, strip_h, dst=0, group=None, out=None, core=None, pad
     library's copy kernel (`vrt_assemble_strips`), enqueued on the same stream: call
     `core.sync()` before reading the frame.  Without it (host tensors, the gloo rehearsal)
     the rows are put back with tensor indexing.  `pad_rows`: rows every rank's buffer is padded to (default
-    and minimum: the rows of the largest part; the same value on every rank)."""
+    and minimum: the rows of the largest part; the same value on every rank).  `pixels="bgr"` (with `core`, for a
+    BGRA8 plane [rows, w, 4] with w a multiple of 4): the rows cross the links without their alpha byte, which is 255
+    on every path of the shader -- packed by `vrt_pack_bgr` before the gather, restored by the reorder kernel
+    (`vrt_assemble_strips_bgr`) behind it: three quarters of the bytes through rank `dst`'s links."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     most = max_strip_rows(h, strip_h, world)
@@ -58,10 +61,22 @@ def gather_frame(packed, h, strip_h, dst=0, group=None, out=None, core=None, pad
         # Everything that touches `packed` runs on the context's stream, behind the trace that fills it: the
         # padding copy (ranks own different row counts when the strips do not divide evenly), the gather and
         # the row reorder.  Buffers made here are used on that stream only and are recorded on it.
+        bgr = pixels == "bgr"
+        if bgr and not (packed.dtype == torch.uint8 and packed.dim() == 3 and packed.shape[2] == 4 and packed.shape[1] % 4 == 0):
+            raise ValueError('pixels="bgr" takes a uint8 [rows, w, 4] plane with w a multiple of 4')
+        # With frames in flight on several streams of the context (vrt_set_frame_overlap) the trace that fills `packed`
+        # may run on another of them: the context's first stream waits for every trace enqueued so far.
+        core.join()
         stream = torch.cuda.ExternalStream(core.stream(), device=packed.device)
         with torch.cuda.stream(stream):
             buf = padded()
             buf.record_stream(stream)
+            if bgr:   # three bytes per pixel from here to the reorder
+                w = buf.shape[1]
+                buf3 = buf.new_empty((pad_rows, w, 3))
+                buf3.record_stream(stream)
+                core.pack_bgr(buf.data_ptr(), buf3.data_ptr(), pad_rows * w)
+                buf = buf3
             if rank != dst:
                 dist.gather(buf, None, dst=dst, group=group)
                 return None
@@ -71,8 +86,11 @@ def gather_frame(packed, h, strip_h, dst=0, group=None, out=None, core=None, pad
             frame = out if out is not None else packed.new_empty((h,) + tuple(packed.shape[1:]))
             if not frame.is_contiguous() or frame.shape[0] != h:
                 raise ValueError("`out` must be a contiguous [h, ...] tensor")
-            row_bytes = frame[0].numel() * frame.element_size()
-            core.assemble_strips(parts.data_ptr(), frame.data_ptr(), row_bytes, h, strip_h, world, pad_rows)
+            if bgr:
+                core.assemble_strips_bgr(parts.data_ptr(), frame.data_ptr(), frame.shape[1], h, strip_h, world, pad_rows)
+            else:
+                row_bytes = frame[0].numel() * frame.element_size()
+                core.assemble_strips(parts.data_ptr(), frame.data_ptr(), row_bytes, h, strip_h, world, pad_rows)
             frame.record_stream(stream)
         return frame
     buf = padded()
@@ -113,6 +131,14 @@ class Comm:
         arr = (self._C.c_void_p * len(packed_ptrs))(*packed_ptrs)
         self._L.check(self._L.lib().vrt_gather_strips(self._comm, arr, gathered_ptr, frame_ptr, row_bytes, h, strip_h,
                                                       part_stride_rows))
+
+    def gather_strips_bgr(self, packed_bgra_ptrs, packed_bgr_ptrs, gathered_bgr_ptr, frame_bgra_ptr, w, h, strip_h, part_stride_rows):
+        """A strip-sharded BGRA8 frame with three bytes per pixel on the links: every core packs its rows into its own
+        BGR8 buffer, the parts are gathered, the root writes the BGRA8 frame in image order."""
+        a = (self._C.c_void_p * len(packed_bgra_ptrs))(*packed_bgra_ptrs)
+        b = (self._C.c_void_p * len(packed_bgr_ptrs))(*packed_bgr_ptrs)
+        self._L.check(self._L.lib().vrt_gather_strips_bgr(self._comm, a, b, gathered_bgr_ptr, frame_bgra_ptr, w, h, strip_h,
+                                                          part_stride_rows))
 
     def close(self):
         if self._comm:

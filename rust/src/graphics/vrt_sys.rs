@@ -65,6 +65,7 @@ extern "C" {
     pub fn vrt_trace_strips(ctx: *mut VrtCtx, cam_col_major: *const f32, w: u32, h: u32, strip_h: u32, part: u32, parts: u32, out: *const VrtOutputs) -> c_int;
     pub fn vrt_strip_rows(h: u32, strip_h: u32, part: u32, parts: u32) -> u32;
     pub fn vrt_assemble_strips(ctx: *mut VrtCtx, gathered: *const c_void, frame: *mut c_void, row_bytes: u32, h: u32, strip_h: u32, parts: u32, part_stride_rows: u32) -> c_int;
+    pub fn vrt_assemble_strips_bgr(ctx: *mut VrtCtx, gathered_bgr: *const c_void, frame_bgra: *mut c_void, w: u32, h: u32, strip_h: u32, parts: u32, part_stride_rows: u32) -> c_int;
     pub fn vrt_pack_bgr(ctx: *mut VrtCtx, bgra: *const c_void, bgr: *mut c_void, pixels: usize) -> c_int;
     pub fn vrt_unpack_bgra(ctx: *mut VrtCtx, bgr: *const c_void, bgra: *mut c_void, pixels: usize) -> c_int;
     pub fn vrt_alloc_host(ctx: *mut VrtCtx, bytes: usize, out: *mut *mut c_void) -> c_int;
@@ -86,6 +87,7 @@ extern "C" {
     pub fn vrt_comm_size(comm: *const VrtComm) -> u32;
     pub fn vrt_gather(comm: *mut VrtComm, send: *const *const c_void, bytes_each: usize, recv_root: *mut c_void) -> c_int;
     pub fn vrt_gather_strips(comm: *mut VrtComm, packed: *const *const c_void, gathered: *mut c_void, frame: *mut c_void, row_bytes: u32, h: u32, strip_h: u32, part_stride_rows: u32) -> c_int;
+    pub fn vrt_gather_strips_bgr(comm: *mut VrtComm, packed_bgra: *const *const c_void, packed_bgr: *const *mut c_void, gathered_bgr: *mut c_void, frame_bgra: *mut c_void, w: u32, h: u32, strip_h: u32, part_stride_rows: u32) -> c_int;
     pub fn vrt_last_error() -> *const c_char;
     pub fn vrt_version() -> *const c_char;
 }

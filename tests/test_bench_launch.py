@@ -64,6 +64,34 @@ def test_single_rank_over_rccl_gathers_packed_pixels():
     assert lines[0]["parity"]["bgra8_sha256_equals_oracle_golden"] is True
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("pixels", ["bgr", "bgra"])
+def test_strip_sharded_frame_single_rank_over_rccl(pixels):
+    """`--shard strips` through RCCL as far as one GPU goes: the rank's strips packed (three bytes per pixel unless bgra),
+    gathered on the context's stream, put back in row order (with the alpha byte again) by the reorder kernel; bench.py
+    itself compares the reassembled frame with the frame traced whole, and the line with the oracle's frozen frame."""
+    p = run_bench("--gpus", "1", "--force-gather", "--shard", "strips", "--steps", "6", "--warmup", "2", "--no-cpu-baseline",
+                  "--no-literal", "--probe", "16", "--gather-pixels", pixels)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = json_lines(p.stdout)
+    assert len(lines) == 1 and lines[0]["scaling"] == "strong"
+    assert lines[0]["gather"]["bytes_per_pixel_on_the_link"] == (3 if pixels == "bgr" else 4)
+    assert lines[0]["parity"]["bgra8_sha256_equals_oracle_golden"] is True
+
+
+@pytest.mark.gpu
+def test_strip_sharded_frame_two_ranks_over_gloo():
+    """The same partition with two ranks on the one GPU (gloo, through host memory): parts of 544 and 536 rows, padded,
+    three bytes per pixel; rank 0's reassembled frame is the frame traced whole (asserted by bench.py) and the oracle's."""
+    p = run_bench("--gpus", "2", "--backend", "gloo", "--shard", "strips", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                  "--probe", "16")
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = json_lines(p.stdout)
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["scaling"] == "strong"
+    assert lines[0]["gather"] == {"bytes_per_pixel_on_the_link": 3, "bytes_per_frame_on_the_links": 544 * 1920 * 3}
+    assert lines[0]["parity"]["bgra8_sha256_equals_oracle_golden"] is True
+
+
 def test_counter_record_the_bench_prices_is_complete():
     """bench.py takes the kernel's bytes, instruction counts and counters per launch from profiles/traffic.json (committed
     counter passes of its own command): both launch modes must be there, and the figures must hang together."""

@@ -10,7 +10,7 @@ import pytest
 import torch
 import torch.distributed as dist
 
-from raytracing_amd import GraphicsCore, Player, TRACE_SKIP, VOXEL_PACKED_U8, scenes, sharding
+from raytracing_amd import GraphicsCore, Player, TRACE_SKIP, VOXEL_PACKED_U8, VrtError, scenes, sharding
 
 pytestmark = pytest.mark.gpu
 
@@ -81,3 +81,30 @@ def test_alpha_is_dropped_and_restored_around_a_transfer():
         from raytracing_amd import VrtError
         with pytest.raises(VrtError):
             g.pack_bgr(frame.data_ptr(), packed.data_ptr(), W * H - 1)
+
+
+@pytest.mark.parametrize("w,h,strip_h,parts", [(1920, 1080, 16, 8), (640, 250, 16, 3), (64, 37, 4, 5)])
+def test_reassembly_of_three_byte_parts_restores_rows_and_alpha(w, h, strip_h, parts):
+    """vrt_assemble_strips_bgr against the two steps it fuses (vrt_assemble_strips on BGR8 rows, then vrt_unpack_bgra):
+    random pixels, ragged last strips, padding rows between the parts; and its argument checks."""
+    from raytracing_amd import sharding
+    with GraphicsCore(grid_n=64, voxel_format=VOXEL_PACKED_U8) as g:
+        stride = sharding.max_strip_rows(h, strip_h, parts) + 2
+        gen = torch.Generator(device="cuda").manual_seed(w * 31 + h)
+        parts3 = torch.randint(0, 256, (parts, stride, w, 3), dtype=torch.uint8, device="cuda", generator=gen)
+        rows3 = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
+        two_steps = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+        fused = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+        g.assemble_strips(parts3.data_ptr(), rows3.data_ptr(), w * 3, h, strip_h, parts, stride)
+        g.unpack_bgra(rows3.data_ptr(), two_steps.data_ptr(), w * h)
+        g.assemble_strips_bgr(parts3.data_ptr(), fused.data_ptr(), w, h, strip_h, parts, stride)
+        g.sync()
+        assert torch.equal(fused, two_steps)
+        assert int(fused[..., 3].min()) == 255
+        for r in range(parts):          # and row by row against the definition
+            rows = sharding.strip_rows(h, strip_h, r, parts)
+            assert torch.equal(fused[torch.as_tensor(rows, device="cuda")][..., :3], parts3[r][:len(rows)])
+        with pytest.raises(VrtError):
+            g.assemble_strips_bgr(parts3.data_ptr(), fused.data_ptr(), w - 1, h, strip_h, parts, stride)
+        with pytest.raises(VrtError):
+            g.assemble_strips_bgr(parts3.data_ptr(), fused.data_ptr(), w, h, strip_h, parts, stride - 3)

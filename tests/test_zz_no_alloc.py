@@ -92,3 +92,99 @@ def test_static_entry_point_with_the_literal_kernel():
         both_ways(g, cam, 640, 480)
         both_ways(g, cam, 320, 200)
         assert g.last_kernel_name() == "literal"
+
+
+def test_static_entry_point_leaves_device_memory_as_it_found_it():
+    """What the entry point claims: no device allocation.  Free device memory (hipMemGetInfo through torch) is the same
+    before and after 200 calls of mixed shapes that include every state change the path has -- tables refilled for
+    other frame shapes, the window moving to another chunk row (the pyramid is re-levelled and the tables refilled),
+    bands, a second context taking turns -- while every buffer the test itself needs exists beforehand."""
+    n = 256
+    p = scenes.pose_b()
+    cams = [scenes.cam16(p), scenes.cam16(Player.at((70.2, 50.9, -40.4), 2.2, -0.6)),      # another chunk in x, y and z
+            scenes.cam16(Player.at((3.3, 90.7, -5.1), 0.4, -1.1))]
+    shapes = [(1920, 1080, 0, 1080), (640, 360, 0, 360), (1280, 720, 100, 333), (333, 217, 0, 217)]
+    with GraphicsCore(grid_n=n, voxel_format=VOXEL_PACKED_U8, trace_mode=TRACE_SKIP) as g, \
+            GraphicsCore(grid_n=160, trace_mode=TRACE_SKIP) as g2:
+        g.generate_window(scenes.window_min(p.get_position(), n))
+        g.reset_distance_field()
+        g2.generate_window(scenes.window_min(p.get_position(), 160))
+        g2.reset_distance_field()
+        out = planes(1080, 1920)
+        ptrs = {k: v.data_ptr() for k, v in out.items()}
+        for cam in cams:                      # one ordinary trace per window position and context: the index is complete for all
+            g.trace_device(cam, 64, 32, 0, 32, ptrs)
+            g2.trace_device(cam, 64, 32, 0, 32, ptrs)
+        g.trace_static_device(cams[0], 64, 32, 0, 32, ptrs)
+        g.sync(); g2.sync()
+        torch.cuda.synchronize()
+        free0, total = torch.cuda.mem_get_info()
+        for i in range(200):
+            w, h, y0, y1 = shapes[i % len(shapes)]
+            core = g2 if i % 7 == 3 else g
+            core.trace_static_device(cams[(i // 5) % len(cams)], w, h, y0, y1, ptrs)
+            if i % 50 == 49:
+                g.sync(); g2.sync()
+                assert torch.cuda.mem_get_info()[0] == free0, i
+        g.sync(); g2.sync()
+        torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info() == (free0, total)
+        # and the last frame is still the right one
+        w, h, y0, y1 = shapes[1]
+        both_ways(g, cams[2], w, h, y0, y1)
+
+
+def test_static_entry_point_keeps_two_contexts_and_two_threads_apart():
+    """Every context of a GPU shares the one static scratch.  Launches of two contexts on their two streams, enqueued
+    back to back without a host wait, come out right (the later stream waits for the earlier launch); and two host
+    threads that call at once never tear the scratch: a call either goes through, and its frame is right, or returns
+    VRT_E_UNSUPPORTED ("in use") with nothing enqueued."""
+    import threading
+    p = scenes.pose_b()
+    cam_a, cam_b = scenes.cam16(p), scenes.cam16(Player.at(p.get_position(), scenes.POSE_B_YAW + 1.3, -0.5))
+    w, h = 640, 360
+    with GraphicsCore(grid_n=160, trace_mode=TRACE_SKIP) as ga, GraphicsCore(grid_n=160, trace_mode=TRACE_SKIP) as gb:
+        for g in (ga, gb):
+            g.generate_window(scenes.window_min(p.get_position(), 160))
+            g.reset_distance_field()
+        want = {}
+        for name, g, cam in (("a", ga, cam_a), ("b", gb, cam_b)):
+            ref = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+            g.trace_device(cam, w, h, 0, h, {"bgra8": ref.data_ptr()})
+            g.sync()
+            want[name] = ref
+        # two streams, no host wait in between
+        fa = [torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda") for _ in range(24)]
+        fb = [torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda") for _ in range(24)]
+        for i in range(24):
+            ga.trace_static_device(cam_a, w, h, 0, h, {"bgra8": fa[i].data_ptr()})
+            gb.trace_static_device(cam_b, w, h, 0, h, {"bgra8": fb[i].data_ptr()})
+        ga.sync(); gb.sync()
+        assert all(torch.equal(f, want["a"]) for f in fa) and all(torch.equal(f, want["b"]) for f in fb)
+
+        # two threads
+        results = {"a": [], "b": []}
+
+        def worker(name, g, cam, frames):
+            for f in frames:
+                try:
+                    g.trace_static_device(cam, w, h, 0, h, {"bgra8": f.data_ptr()})
+                    results[name].append(True)
+                except VrtError as e:
+                    assert e.code == L.VRT_E_UNSUPPORTED and "in use" in str(e), str(e)
+                    results[name].append(False)
+
+        for f in fa + fb:
+            f.zero_()
+        torch.cuda.synchronize()
+        ta = threading.Thread(target=worker, args=("a", ga, cam_a, fa * 20))
+        tb = threading.Thread(target=worker, args=("b", gb, cam_b, fb * 20))
+        ta.start(); tb.start(); ta.join(); tb.join()
+        ga.sync(); gb.sync()
+        for name, frames in (("a", fa), ("b", fb)):
+            ok = results[name]
+            assert len(ok) == 480 and any(ok)
+            for i, f in enumerate(frames):          # a buffer some successful call wrote holds the frame; the others are untouched
+                wrote = any(ok[i + 24 * r] for r in range(20))
+                assert torch.equal(f, want[name]) if wrote else int(f.max()) == 0, (name, i)
+        print("refused calls:", results["a"].count(False), results["b"].count(False))

@@ -180,6 +180,7 @@ struct vrt_ctx {
     //   VRT_SECONDARY=pixel vrt_trace_secondary runs every pixel's rays on the pixel's own lane instead of staging
     //                       and binning the workgroup's rays in LDS (same outputs; for A/B measurements)
     uint32_t    knob_tile_log2h = 2;
+    uint32_t    knob_tile_lanes = 0;     // VRT_TILE_LANES=32|64: lanes of a wavefront that trace (0: the library chooses per launch)
     bool        knob_no_row_order = false, knob_sched_debug = false, knob_secondary_binned = true;
     int32_t     knob_row_block0 = -1;
     // staging for host-resident outputs
@@ -370,13 +371,13 @@ int attach_row_sched(vrt_ctx *c, Scratch &S, vrt::TraceParams &p, uint32_t kind,
     if (c->knob_row_block0 >= 0) { p.sched.fixed_start = c->knob_row_block0; S.sched_sig[0] = 0; return VRT_OK; }
     const uint32_t block_h = 4u << p.tile_log2h;
     const uint32_t grid_y = (p.rows.rows + block_h - 1) / block_h;
-    const uint32_t grid_x = (p.w + (64u >> p.tile_log2h) - 1) / (64u >> p.tile_log2h);
+    const uint32_t grid_x = (p.w + (p.tile_lanes >> p.tile_log2h) - 1) / (p.tile_lanes >> p.tile_log2h);
     if (!S.sched || grid_y == 0 || grid_y > kSchedRows || (uint64_t)grid_x * grid_y * 4 > S.sched_capacity || c->knob_no_row_order) {
         S.sched_sig[0] = 0;
         return VRT_OK;
     }
     const uint64_t sig[5] = {
-        ((uint64_t)kind << 56) | ((uint64_t)p.tile_log2h << 48) | ((uint64_t)p.w << 24) | (uint64_t)p.h,
+        ((uint64_t)kind << 56) | ((uint64_t)(p.tile_lanes == 32u) << 55) | ((uint64_t)p.tile_log2h << 48) | ((uint64_t)p.w << 24) | (uint64_t)p.h,
         ((uint64_t)p.rows.y0 << 32) | (uint64_t)p.rows.rows,
         ((uint64_t)p.rows.strip_h << 40) | ((uint64_t)p.rows.part << 20) | (uint64_t)p.rows.parts,
         (uint64_t)(horizon_packed_row(p.m, p.w, p.h, p.rows) / block_h),
@@ -459,6 +460,7 @@ int prepare_trace(vrt_ctx *c, Scratch &S, hipStream_t st, bool may_build, const 
     for (uint32_t v = c->n / 4; v > 1; v >>= 1) p.nc_log2 += 1;
     p.max_steps = c->max_steps;
     p.tile_log2h = c->knob_tile_log2h;
+    p.tile_lanes = 64;   // (do_trace halves it for a primary launch that would leave most of the GPU's wavefront slots empty)
     p.need_cap = c->max_steps < 3u * c->n ? 1u : 0u;
     for (int k = 0; k < 3; ++k) {
         const int n = (int)c->n;
@@ -534,6 +536,7 @@ int do_trace(vrt_ctx *c, const float *cam, uint32_t w, uint32_t h, const vrt::Ro
     if (timed && c->ev_pending == kEventRing) { int rc = drain_events(c); if (rc != VRT_OK) return rc; }
     const int e = c->ev_pending;
     if (timed) HIP_TRY(hipEventRecord(c->ev0[e], st));
+    if (use_skip && p.tile_log2h <= 4) p.tile_lanes = c->knob_tile_lanes ? c->knob_tile_lanes : 64;
     if (use_skip) { int rc = attach_row_sched(c, S, p, 1, c->overlap > 1 && out->memory == VRT_MEM_DEVICE); if (rc != VRT_OK) return rc; }
     if (use_skip) { HIP_TRY(vrt::launch_trace_skip(p, c->voxel_bytes, st)); c->last_kernel = "skip"; }
     else          { HIP_TRY(vrt::launch_trace_literal(p, c->voxel_bytes, st)); c->last_kernel = "literal"; }
@@ -585,7 +588,8 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out)
     c->max_steps   = cfg->max_steps ? cfg->max_steps : 4 * cfg->grid_n;
     c->trace_mode  = cfg->trace_mode;
     for (int i = 0; i < kEventRing; ++i) { c->ev0[i] = nullptr; c->ev1[i] = nullptr; }
-    if (const char *v = std::getenv("VRT_TILE_LOG2H")) c->knob_tile_log2h = (uint32_t)std::atoi(v) % 7u;
+    if (const char *v = std::getenv("VRT_TILE_LOG2H")) c->knob_tile_log2h = (uint32_t)std::atoi(v) % 6u;
+    if (const char *v = std::getenv("VRT_TILE_LANES")) c->knob_tile_lanes = std::atoi(v) == 32 ? 32 : (std::atoi(v) == 64 ? 64 : 0);
     if (const char *v = std::getenv("VRT_NO_ROW_ORDER")) c->knob_no_row_order = v[0] == '1';
     if (const char *v = std::getenv("VRT_ROW_BLOCK0")) c->knob_row_block0 = std::atoi(v);
     if (const char *v = std::getenv("VRT_SCHED_DEBUG")) c->knob_sched_debug = v[0] == '1';

@@ -59,7 +59,9 @@ struct TraceParams {
     int32_t  n_pow2_mask;  // n-1 if n is a power of two, else -1
     int32_t  nc_log2;      // log2(n / 4) if n is a power of two
     uint32_t max_steps;
-    uint32_t tile_log2h;   // wave tile is (64 >> tile_log2h) x (1 << tile_log2h) pixels, 0..6
+    uint32_t tile_log2h;   // wave tile is (tile_lanes >> tile_log2h) x (1 << tile_log2h) pixels, 0..5
+    uint32_t tile_lanes;   // 64, or 32: wavefronts filled by half (a launch too small to fill the GPU: twice the wavefronts, each
+                           // as long as the longest of 32 rays instead of 64)
     uint32_t need_cap;     // max_steps can end a regular ray (max_steps < 3n): test it in the skip loop
     RowSched sched;
     // world

@@ -781,7 +781,8 @@ template <typename PARAMS>
 VRT_DEV bool pixel_of_thread(const PARAMS &P, unsigned by, unsigned tid, unsigned &col, unsigned &q, unsigned &row)
 {
     const unsigned wave = tid >> 6, lane = tid & 63;
-    const unsigned lh = P.tile_log2h, tw = 64u >> lh;
+    const unsigned lanes = P.tile_lanes, lanes_log2 = lanes == 64u ? 6u : 5u;
+    const unsigned lh = P.tile_log2h, tw = lanes >> lh;
 #ifdef VRT_XCD_STRIPES
     // An experiment (measured, not adopted): workgroups are dealt round-robin over the eight XCDs, each with an L2 of its
     // own, so with a row of G workgroups (G a multiple of 8) workgroup x runs on XCD x % 8; tile column
@@ -791,8 +792,8 @@ VRT_DEV bool pixel_of_thread(const PARAMS &P, unsigned by, unsigned tid, unsigne
     const unsigned bx = blockIdx.x;
 #endif
     col = bx * tw + (lane & (tw - 1));
-    q   = ((by * 4 + wave) << lh) + (lane >> (6 - lh));
-    if (col >= P.w || q >= P.rows.rows) return false;
+    q   = ((by * 4 + wave) << lh) + (lane >> (lanes_log2 - lh));
+    if (lane >= lanes || col >= P.w || q >= P.rows.rows) return false;
     if (P.rows.strip_h == 0) {
         row = P.rows.y0 + q;
     } else {
@@ -1629,7 +1630,7 @@ static int trace_form(const TraceParams &p)
 
 static dim3 trace_grid(const TraceParams &p)
 {
-    const unsigned tw = 64u >> p.tile_log2h, bh = 4u << p.tile_log2h;
+    const unsigned tw = p.tile_lanes >> p.tile_log2h, bh = 4u << p.tile_log2h;
     return dim3((p.w + tw - 1) / tw, (p.rows.rows + bh - 1) / bh, 1);
 }
 

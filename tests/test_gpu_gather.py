@@ -57,6 +57,34 @@ def test_padded_strip_buffers_are_gathered_behind_the_trace(single_rank_rccl):
             sharding.gather_frame(packed, H, strip_h, dst=0, core=g, pad_rows=rows - 1)
 
 
+@pytest.mark.parametrize("pixels", ["bgra", "bgr"])
+def test_gather_waits_for_traces_on_every_stream_of_the_context(single_rank_rccl, pixels):
+    """With two frames in flight (vrt_set_frame_overlap(2)) the strip trace that fills the packed buffer may run on the
+    context's second stream; gather_frame(core=...) joins the context's streams before it touches the buffer.  Two
+    packed buffers are traced back to back (one per stream) and each is gathered right away, 16 rounds; with pixels="bgr"
+    the rows also cross the gather without their alpha byte."""
+    W, H, strip_h, n = 1920, 1080, 16, 256
+    p0 = scenes.pose_b()
+    with GraphicsCore(grid_n=n, voxel_format=VOXEL_PACKED_U8, trace_mode=TRACE_SKIP) as g:
+        g.generate_window(scenes.window_min(p0.get_position(), n))
+        g.reset_distance_field()
+        g.set_frame_overlap(2)
+        packed = [torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+        whole = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        for i in range(16):
+            cams = [scenes.cam16(Player.at(p0.get_position(), scenes.POSE_B_YAW + 0.21 * i + 0.1 * j, scenes.POSE_B_PITCH)) for j in range(2)]
+            for j in range(2):      # one launch per stream of the context
+                g.trace_strips_device(cams[j], W, H, strip_h, 0, 1, {"bgra8": packed[j].data_ptr()})
+            frames = [sharding.gather_frame(packed[j], H, strip_h, dst=0, core=g, pad_rows=H + 8, pixels=pixels) for j in range(2)]
+            g.sync()
+            torch.cuda.synchronize()
+            for j in range(2):
+                g.trace_device(cams[j], W, H, 0, H, {"bgra8": whole.data_ptr()})
+                g.sync()
+                assert torch.equal(frames[j], whole), (i, j)
+
+
 def test_alpha_is_dropped_and_restored_around_a_transfer():
     """vrt_pack_bgr / vrt_unpack_bgra on a traced frame (alpha 255 everywhere, as the shader stores it) and on random
     bytes (the alpha byte is not carried: it comes back as 255)."""

@@ -275,6 +275,11 @@ int vrt_kernel_time_reset(vrt_ctx *ctx);
  * every frame; `launches` of vrt_kernel_time then counts the timed launches only.  every_n = 0 turns
  * the timing off. */
 int vrt_kernel_time_sampling(vrt_ctx *ctx, uint32_t every_n);
+/* Workgroups (256 threads, four wavefronts) of a trace kernel that one compute unit of the context's GPU holds at once,
+ * by the runtime's own occupancy calculation: kind 0 the primary skip kernel, 1 the LDS-binned secondary-ray kernel,
+ * 2 the literal kernel.  The kernels are built to reach 8 (every wavefront slot of the CU); a build that loses that --
+ * a register or 20 KB of LDS more -- slows down without failing any test of its pixels, so a test asks here. */
+int vrt_kernel_occupancy(vrt_ctx *ctx, uint32_t kind, int32_t *workgroups_per_cu);
 /* Name of the kernel the last vrt_trace launched ("literal" or "skip"). */
 const char *vrt_last_kernel_name(vrt_ctx *ctx);
 

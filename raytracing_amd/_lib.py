@@ -78,6 +78,7 @@ SYMBOLS = {
     "vrt_kernel_time": (C.c_int, [_CTX, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "vrt_kernel_time_reset": (C.c_int, [_CTX]),
     "vrt_kernel_time_sampling": (C.c_int, [_CTX, C.c_uint32]),
+    "vrt_kernel_occupancy": (C.c_int, [_CTX, C.c_uint32, C.POINTER(C.c_int32)]),
     "vrt_last_kernel_name": (C.c_char_p, [_CTX]),
     "vrt_stream": (C.c_void_p, [_CTX]),
     "vrt_device": (C.c_int, [_CTX]),

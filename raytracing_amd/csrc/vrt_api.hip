@@ -1039,6 +1039,17 @@ int vrt_kernel_time_sampling(vrt_ctx *c, uint32_t every_n)
     return VRT_OK;
 }
 
+int vrt_kernel_occupancy(vrt_ctx *c, uint32_t kind, int32_t *workgroups_per_cu)
+{
+    if (!c || !workgroups_per_cu) return fail(VRT_E_INVALID_ARG, "null argument");
+    if (kind > 2u) return fail(VRT_E_INVALID_ARG, "kernel kind %u (0: skip, 1: binned secondary, 2: literal)", kind);
+    HIP_TRY(hipSetDevice(c->device));
+    int n = 0;
+    HIP_TRY(vrt::trace_kernel_occupancy((int)kind, &n));
+    *workgroups_per_cu = n;
+    return VRT_OK;
+}
+
 const char *vrt_last_kernel_name(vrt_ctx *c) { return c ? c->last_kernel : "none"; }
 void *vrt_stream(vrt_ctx *c) { return c ? (void *)c->stream : nullptr; }
 int vrt_device(vrt_ctx *c) { return c ? c->device : -1; }

@@ -108,6 +108,8 @@ hipError_t launch_trace_skip(const TraceParams &p, int voxel_bytes, hipStream_t 
 hipError_t launch_trace_secondary(const TraceParams &p, int voxel_bytes, bool binned, uint8_t *shadow, uint8_t *ao,
                                   uint32_t *sec_steps, hipStream_t s);
 
+hipError_t trace_kernel_occupancy(int kind, int *workgroups_per_cu);  // kind 0: skip, 1: binned secondary, 2: literal
+
 // world kernels
 hipError_t launch_terrain(void *block, int voxel_bytes, int n, int x0, int y0, int z0,
                           int ex, int ey, int ez, hipStream_t s);

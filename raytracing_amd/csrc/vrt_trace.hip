@@ -1388,6 +1388,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 // Measured on 1920 x 1080 over the 1024^3 terrain, 5.9 M secondary rays: 32.3 Grays/s, 0.67 of the lanes active
 // per vector instruction, against 22.2 Grays/s and 0.45 for k_trace_secondary.
 constexpr unsigned SEC_BINS = 17;  // 16 elevation classes of ambient-occlusion rays + the shadow rays
+constexpr unsigned SEC_AO_HIT = 1u << 24, SEC_SHADOW_HIT = 1u << 28;  // a ray's hit in its pixel's accumulator, above the iterations
 #ifndef VRT_SEC_REFILL
 #define VRT_SEC_REFILL 24
 #endif
@@ -1403,19 +1404,22 @@ constexpr unsigned SEC_REFILL = VRT_SEC_REFILL;  // free lanes at which a wavefr
 template <typename T, int FORM>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VRT_SEC_WAVES, 8))) void k_trace_secondary_binned(const TraceParams P, uint8_t *shadow, uint8_t *ao, uint32_t *sec_steps)
 {
-    __shared__ float          s_org[3][256];   // origin of the pixel's secondary rays
-    __shared__ unsigned char  s_face[256];     // face of the primary hit, 0xff: no hit
-    __shared__ unsigned       s_steps[256];    // loop iterations summed over the pixel's rays
-    __shared__ unsigned       s_hits[256];     // bit 0: the shadow ray hit; bits 8..: ambient-occlusion rays that hit
+    // 20 112 bytes: eight workgroups (32 wavefronts, the most a CU holds) fit a CU's 160 KB with the 20 480 each may take
+    __shared__ float4         s_org[256];      // origin of the pixel's secondary rays; .w: face of the primary hit (bits), 0xff: no hit
+    __shared__ unsigned       s_acc[256];      // per pixel: loop iterations summed over its rays (bits 0..23: at most 5 x 4 x 4096),
+                                               // ambient-occlusion rays that hit (bits 24..27), the shadow ray hit (bit 28)
     __shared__ unsigned short s_ray[5 * 256];  // the sorted list: pixel | ray index << 8
     __shared__ float          s_dir[3][4 * 256];  // directions of the ambient-occlusion rays, by position in the list
     __shared__ unsigned       s_count[SEC_BINS], s_base[SEC_BINS], s_next, s_total;
+    static_assert(sizeof(float4) * 256 + sizeof(unsigned) * 256 + sizeof(unsigned short) * 5 * 256 + sizeof(float) * 3 * 4 * 256 +
+                      sizeof(unsigned) * (2 * SEC_BINS + 2) <= 20480,
+                  "the binned secondary-ray kernel may take 20 KB of LDS: a ninth of a byte more and a CU holds seven workgroups instead of eight");
 
     const unsigned tid = threadIdx.x;
     const unsigned by = sched_row(P);
     if (tid < SEC_BINS) s_count[tid] = 0;
     if (tid == 0) s_next = 0;
-    s_steps[tid] = 0; s_hits[tid] = 0; s_face[tid] = 0xff;
+    s_acc[tid] = 0; s_org[tid].w = __uint_as_float(0xffu);
     __syncthreads();
 
     // ---- phase 1: the primary ray of this lane's pixel
@@ -1448,10 +1452,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VRT_SEC_WAV
         hit = H.hit != 0;
         if (hit) {
             const float nk = (float)(-H.sk);
-            s_org[0][tid] = H.hx + (H.k == 0 ? nk : 0.0f) * 1e-3f;
-            s_org[1][tid] = H.hy + (H.k == 1 ? nk : 0.0f) * 1e-3f;
-            s_org[2][tid] = H.hz + (H.k == 2 ? nk : 0.0f) * 1e-3f;
-            s_face[tid] = (unsigned char)(2 * H.k + (H.sk < 0 ? 1 : 0));
+            s_org[tid] = make_float4(H.hx + (H.k == 0 ? nk : 0.0f) * 1e-3f, H.hy + (H.k == 1 ? nk : 0.0f) * 1e-3f,
+                                     H.hz + (H.k == 2 ? nk : 0.0f) * 1e-3f, __uint_as_float((unsigned)(2 * H.k + (H.sk < 0 ? 1 : 0))));
             // direction classes: ray j + 1 has elevation sqrt(1 - u1) over its surface, u1 = (hash >> 8) * 2^-24
             // (secondary_dir): class = the top four bits of u1, counted from the shallow end
             unsigned hsh = pcg_hash(0x5EEDu ^ (row * P.w + col));
@@ -1467,7 +1469,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VRT_SEC_WAV
 #endif
                 hsh = pcg_hash(hsh); hsh = pcg_hash(hsh);
             }
-            for (unsigned j = 0; j < 5; ++j) atomicAdd(&s_count[(bins >> (5u * j)) & 31u], 1u);
+            // (the shadow rays of a wavefront are counted and placed by one add: 64 lanes on one counter take turns)
+            const unsigned long long hm = __ballot(1);
+            if (__builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0u)) == 0)
+                atomicAdd(&s_count[SEC_BINS - 1], (unsigned)__popcll(hm));
+            for (unsigned j = 1; j < 5; ++j) atomicAdd(&s_count[(bins >> (5u * j)) & 31u], 1u);
         }
     }
     __syncthreads();
@@ -1490,8 +1496,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VRT_SEC_WAV
     const unsigned ao_base = 0;
 #endif
     if (hit) {
-        const int face = (int)s_face[tid];
-        s_ray[atomicAdd(&s_base[SEC_BINS - 1], 1u)] = (unsigned short)tid;
+        const int face = (int)__float_as_uint(s_org[tid].w);
+        {
+            const unsigned long long hm = __ballot(1);
+            const unsigned r = __builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0u));
+            unsigned b0 = 0;
+            if (r == 0) b0 = atomicAdd(&s_base[SEC_BINS - 1], (unsigned)__popcll(hm));
+            b0 = (unsigned)__builtin_amdgcn_readfirstlane((int)b0);  // (the first active lane is the one that added)
+            s_ray[b0 + r] = (unsigned short)tid;
+        }
         for (unsigned j = 0; j < 4; ++j) {
             const unsigned at = atomicAdd(&s_base[(bins >> (5u * (j + 1u))) & 31u], 1u);
             s_ray[at] = (unsigned short)(tid | ((j + 1u) << 8));
@@ -1522,15 +1535,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VRT_SEC_WAV
         // other free lanes' results, rather than in the trip it ended in with the few lanes that ended with it
         auto deliver = [&]() {
             if (mine != NO_RAY) {
-                const unsigned pix = mine & 255u;
-                atomicAdd(&s_steps[pix], ray.steps_done());
-                if (ray.hit) atomicAdd(&s_hits[pix], (mine >> 8) == 0 ? 1u : 256u);
+                const unsigned pix = mine & 255u;   // one add carries the ray's iterations and its hit
+                atomicAdd(&s_acc[pix], ray.steps_done() + (ray.hit ? ((mine >> 8) == 0 ? SEC_SHADOW_HIT : SEC_AO_HIT) : 0u));
                 mine = NO_RAY;
             }
         };
         unsigned trips = 0;     // wave uniform: trips of the traversal loop this wavefront ran
 #ifdef VRT_DIAG_SEC_UTIL
-        unsigned dRefills = 0, dRefillLanes = 0, dLive = 0, dBegun = 0;
+        unsigned dRefills = 0, dRefillLanes = 0, dLive = 0, dBegun = 0, dTailTrips = 0, dTailLive = 0;
 #endif
         bool     drained = false;  // wave uniform: the list has no ray left for this wavefront
         for (;;) {
@@ -1554,20 +1566,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VRT_SEC_WAV
                     const unsigned dat = is_ao ? at - ao_base : 0u;
                     const float sdx = is_ao ? s_dir[0][dat] : lightx, sdy = is_ao ? s_dir[1][dat] : lighty,
                                 sdz = is_ao ? s_dir[2][dat] : lightz;
-                    const float sox = s_org[0][pix], soy = s_org[1][pix], soz = s_org[2][pix];
+                    const float4 so = s_org[pix];   // (one 16-byte read)
+                    const float sox = so.x, soy = so.y, soz = so.z;
                     if (FORM == FORM_CAPPED) {  // the one-step-per-trip form is not resumable: the whole ray here
                         RayHit S;
                         traverse_skip<T>(P, sox, soy, soz, sdx, sdy, sdz, lox, loy, loz, upx, upy, upz, S);
-                        atomicAdd(&s_steps[pix], S.steps);
-                        if (S.hit) atomicAdd(&s_hits[pix], j == 0 ? 1u : 256u);
+                        atomicAdd(&s_acc[pix], S.steps + (S.hit ? (j == 0 ? SEC_SHADOW_HIT : SEC_AO_HIT) : 0u));
                     } else if (ray_is_regular(sdx, sdy, sdz)) {
                         ray.template begin<false>(P, sox, soy, soz, sdx, sdy, sdz, lox, loy, loz, f2i_small(floorf(sox)),
                                                   f2i_small(floorf(soy)), f2i_small(floorf(soz)), 0u);
                         mine = rec;  // (a ray that starts outside the loaded area is not live and is delivered as it is)
                     } else {
                         const unsigned r = degenerate_ray<T, FORM>(params, sox, soy, soz, sdx, sdy, sdz);
-                        atomicAdd(&s_steps[pix], r & 0x7fffffffu);
-                        if (r >> 31) atomicAdd(&s_hits[pix], j == 0 ? 1u : 256u);
+                        atomicAdd(&s_acc[pix], (r & 0x7fffffffu) + ((r >> 31) ? (j == 0 ? SEC_SHADOW_HIT : SEC_AO_HIT) : 0u));
                     }
                 }
             }
@@ -1578,6 +1589,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VRT_SEC_WAV
             trips += 1u;
 #ifdef VRT_DIAG_SEC_UTIL
             dLive += ray.live ? 1u : 0u;
+            if (drained) { dTailTrips += 1u; dTailLive += ray.live ? 1u : 0u; }
             ray.dAx += __any((ray.live && (ray.d != 0 || ray.entry() != 0)) ? 1 : 0) ? 1u : 0u;
 #endif
             if (ray.live) ray.template trip<SEC_FOLD>(P);
@@ -1589,13 +1601,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VRT_SEC_WAV
         if (sec_steps) {
             auto wsum = [](unsigned v) { for (int o = 32; o > 0; o >>= 1) v += (unsigned)__shfl_xor((int)v, o); return v; };
             const unsigned sA = wsum(ray.dA), sB1 = wsum(ray.dB1), sB2 = wsum(ray.dB2), sLive = wsum(dLive), sBegun = wsum(dBegun);
-            const unsigned sNear = wsum(ray.dNear), sNearX = wsum(ray.dNearX);
+            const unsigned sNear = wsum(ray.dNear), sNearX = wsum(ray.dNearX), sTailLive = wsum(dTailLive);
             if (lane == 0) {
                 atomicAdd(&sec_steps[0], trips); atomicAdd(&sec_steps[1], sLive); atomicAdd(&sec_steps[2], sA);
                 atomicAdd(&sec_steps[3], sB1); atomicAdd(&sec_steps[4], sB2); atomicAdd(&sec_steps[5], ray.dAx);
                 atomicAdd(&sec_steps[6], dRefills); atomicAdd(&sec_steps[7], dRefillLanes); atomicAdd(&sec_steps[8], sBegun);
                 atomicAdd(&sec_steps[9], 1u);
                 atomicAdd(&sec_steps[10], sNear); atomicAdd(&sec_steps[11], sNearX);
+                atomicAdd(&sec_steps[12], dTailTrips); atomicAdd(&sec_steps[13], sTailLive);
             }
         }
 #endif
@@ -1608,9 +1621,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VRT_SEC_WAV
     // ---- phase 3: every lane stores its own pixel (coordinates worked out again rather than kept across the phases)
     if (pixel_of_thread(P, by, opaque(tid), col, q, row)) {
         const size_t i = (size_t)q * P.w + col;
-        if (shadow) shadow[i] = (uint8_t)(s_hits[tid] & 1u);
-        if (ao) ao[i] = (uint8_t)(s_hits[tid] >> 8);
-        if (sec_steps) sec_steps[i] = s_steps[tid];
+        const unsigned acc = s_acc[tid];
+        if (shadow) shadow[i] = (uint8_t)((acc >> 28) & 1u);
+        if (ao) ao[i] = (uint8_t)((acc >> 24) & 15u);
+        if (sec_steps) sec_steps[i] = acc & 0xffffffu;
     }
     if (P.sched.cost) {
         sched_end(P, by, work);
@@ -1667,6 +1681,18 @@ hipError_t launch_trace_secondary(const TraceParams &p, int voxel_bytes, bool bi
     }
 #undef VRT_LAUNCH_SECONDARY
     return hipGetLastError();
+}
+
+// Workgroups of 256 threads of one trace kernel that a compute unit holds at once (registers, LDS and wavefront slots
+// taken together), as the runtime works it out for the current device: kind 0 the primary skip kernel, 1 the binned
+// secondary-ray kernel, 2 the literal kernel; the u8 / power-of-two instances.  Eight (32 wavefronts) is what the
+// kernels are built for.
+hipError_t trace_kernel_occupancy(int kind, int *workgroups_per_cu)
+{
+    const void *k = kind == 0   ? reinterpret_cast<const void *>(&k_trace_skip<uint8_t, FORM_POW2>)
+                    : kind == 1 ? reinterpret_cast<const void *>(&k_trace_secondary_binned<uint8_t, FORM_POW2>)
+                                : reinterpret_cast<const void *>(&k_trace_literal<uint8_t, false>);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(workgroups_per_cu, k, 256, 0);
 }
 
 hipError_t launch_trace_skip(const TraceParams &p, int voxel_bytes, hipStream_t s)

@@ -270,6 +270,12 @@ class GraphicsCore:
         """The context's first stream (stream()) waits for every trace enqueued so far."""
         L.check(L.lib().vrt_join(self._ctx))
 
+    def kernel_occupancy(self, kind):
+        """Workgroups of a trace kernel (0: skip, 1: binned secondary, 2: literal) one compute unit holds at once."""
+        n = C.c_int32()
+        L.check(L.lib().vrt_kernel_occupancy(self._ctx, int(kind), C.byref(n)))
+        return n.value
+
     def kernel_time(self):
         ms, n = C.c_double(), C.c_uint64()
         L.check(L.lib().vrt_kernel_time(self._ctx, C.byref(ms), C.byref(n)))

@@ -79,6 +79,7 @@ extern "C" {
     pub fn vrt_kernel_time(ctx: *mut VrtCtx, total_ms: *mut f64, launches: *mut u64) -> c_int;
     pub fn vrt_kernel_time_reset(ctx: *mut VrtCtx) -> c_int;
     pub fn vrt_kernel_time_sampling(ctx: *mut VrtCtx, every_n: u32) -> c_int;
+    pub fn vrt_kernel_occupancy(ctx: *mut VrtCtx, kind: u32, workgroups_per_cu: *mut i32) -> c_int;
     pub fn vrt_last_kernel_name(ctx: *mut VrtCtx) -> *const c_char;
     pub fn vrt_stream(ctx: *mut VrtCtx) -> *mut c_void;
     pub fn vrt_device(ctx: *mut VrtCtx) -> c_int;

@@ -112,3 +112,15 @@ def test_gpu_secondary_with_a_small_step_cap(kernel, monkeypatch):
     for k in ("shadow", "ao", "sec_steps"):
         assert np.array_equal(got[k], want[k]), k
     assert want["sec_steps"].max() >= cap and want["shadow"].any()
+
+
+@pytest.mark.gpu
+def test_trace_kernels_keep_eight_workgroups_per_compute_unit():
+    """The skip kernel is held to 64 registers and the binned secondary-ray kernel to 20 KB of LDS so that a compute unit
+    holds eight workgroups of either (all 32 wavefront slots); a build that loses one still traces every pixel right,
+    so the runtime's occupancy calculation is asked directly."""
+    from raytracing_amd import GraphicsCore, VOXEL_PACKED_U8
+    with GraphicsCore(grid_n=64, voxel_format=VOXEL_PACKED_U8) as g:
+        assert g.kernel_occupancy(0) == 8
+        assert g.kernel_occupancy(1) == 8
+        assert g.kernel_occupancy(2) >= 8

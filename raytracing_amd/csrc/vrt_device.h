@@ -42,11 +42,21 @@ VRT_DEV int f2i_floor(float x)
 
 // |a| * m + |b| as one fused multiply-add with the magnitudes taken by the instruction's own operand modifiers (written
 // out because the compiler pairs two such operations into a packed instruction, which has no magnitude modifier, and
-// pays four extra instructions for the pair).  The result only steers which of two exact paths a lane takes.
+// pays four extra instructions for the pair; the factor in a vector register: an operand from a scalar register halves
+// the instruction's issue rate on this chip).  The result only steers which of two exact paths a lane takes.
 VRT_DEV float fma_abs(float a, float m, float b)
 {
     float r;
-    asm("v_fma_f32 %0, |%1|, %2, |%3|" : "=v"(r) : "v"(a), "s"(m), "v"(b));
+    asm("v_fma_f32 %0, |%1|, %2, |%3|" : "=v"(r) : "v"(a), "v"(m), "v"(b));
+    return r;
+}
+
+// min(max(v, lo), hi) for lo <= hi, as the one instruction the hardware has for it (the median of the three; the compiler
+// forms it only when it can see that lo <= hi).
+VRT_DEV int clamp_ordered(int v, int lo, int hi)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(hi));
     return r;
 }
 

@@ -393,7 +393,7 @@ template <typename T, bool POW2>
 struct CellRay {
     // per ray constants (mirrored frame)
     float rnx, rny, rnz, dnx, dny, dnz, inx, iny, inz, thr0x, thr0y, thr0z;
-    int   lnx, lny, lnz, ln1x, ln1y, ln1z, smx, smy, smz;  // (ln1 = ln + 1)
+    int   lnx, lny, lnz, ln1x, ln1y, ln1z, smx, smy, smz;  // (ln1 = ln + 1 + PLANE_BIAS, see plane_float)
     unsigned dsel;  // byte selector (v_perm_b32) of this ray's octant distance in the record's two distance words
     // state
     int      wx, wy, wz, w0, k, d, bit;
@@ -407,6 +407,12 @@ struct CellRay {
     // the wavefront ran phase A / phase B at all (wave uniform, counted by every lane)
     unsigned dA = 0, dB1 = 0, dB2 = 0, dAx = 0, dBx = 0, dNear = 0, dNearX = 0;  // lanes near a plane; trips that ran the settling code
 #endif
+
+    // float(i) of a plane coordinate |i| < 2^22 that arrives with PLANE_BIAS added: the biased integer is the bit pattern of
+    // 1.5 * 2^23 + i, and taking 1.5 * 2^23 off is exact -- an integer add and a float subtract, both of which this chip
+    // issues at twice the rate of the conversion.  (Plane coordinates are window coordinates: |i| <= 2^20 + 2 * 4096.)
+    static constexpr int PLANE_BIAS = 0x4B400000;
+    static VRT_DEV float plane_float(int biased) { return __int_as_float(biased) - 12582912.0f; }
 
     // entry of the pyramid word for voxel level j (0..3): bytes 2j, 2j + 1 of the 64-bit word, cut out by one
     // byte permute (selector bytes: 0..3 = pyr_lo, 4..7 = pyr_hi, 0x0c = zero).  The selector's constant half is OR-ed
@@ -490,7 +496,7 @@ struct CellRay {
         // across the loop and takes the magnitude again in every trip)
         asm volatile("" : "+v"(dnx), "+v"(dny), "+v"(dnz), "+v"(inx), "+v"(iny), "+v"(inz));
         lnx = px ? lox : -lox; lny = py ? loy : -loy; lnz = pz ? loz : -loz;
-        ln1x = lnx + 1; ln1y = lny + 1; ln1z = lnz + 1;
+        ln1x = lnx + 1 + PLANE_BIAS; ln1y = lny + 1 + PLANE_BIAS; ln1z = lnz + 1 + PLANE_BIAS;
         const int oct = (px ? 1 : 0) | (py ? 2 : 0) | (pz ? 4 : 0);
         dsel = 0x0c0c0c00u | (unsigned)oct;  // byte `oct` of {r.z, r.w}, zero extended
         // margin of the exit-point test, as 0.5 - VRT_MARGIN * (|pos| + |origin| + 1) = thr0 - VRT_MARGIN * |pos|
@@ -574,9 +580,9 @@ struct CellRay {
                 fwz = min((wz | 3) + r4, whiz);
             }
             // plane parameters of the box's far faces (ln1 = ln + 1: the plane behind anchor fw)
-            const float tx = ((float)(fwx + ln1x) - rnx) * inx;
-            const float ty = ((float)(fwy + ln1y) - rny) * iny;
-            const float tz = ((float)(fwz + ln1z) - rnz) * inz;
+            const float tx = (plane_float(fwx + ln1x) - rnx) * inx;
+            const float ty = (plane_float(fwy + ln1y) - rny) * iny;
+            const float tz = (plane_float(fwz + ln1z) - rnz) * inz;
             // util.glsl:28-42 on finite values (an ordinary ray's, or +inf on a frozen axis): y wins over x only when
             // smaller, z over both only when smaller; the winner's value is the minimum
             const float txy = __builtin_fminf(tx, ty);
@@ -606,9 +612,9 @@ struct CellRay {
             // exit point lies on that plane up to rounding), so the clamp yields the last and the step is a carry --
             // added here, next to the comparisons it comes from, where it costs no instruction of its own.
             const int ox = wx, oy = wy, oz = wz;
-            wx = min(max(vx, ox), fwx) + (kx ? 1 : 0);
-            wy = min(max(vy, oy), fwy) + (ky ? 1 : 0);
-            wz = min(max(vz, oz), fwz) + (cz ? 1 : 0);
+            wx = clamp_ordered(vx, ox, fwx) + (kx ? 1 : 0);   // (a box's last anchor is not before the current one)
+            wy = clamp_ordered(vy, oy, fwy) + (ky ? 1 : 0);
+            wz = clamp_ordered(vz, oz, fwz) + (cz ? 1 : 0);
             if (((int)nearx | (int)neary | (int)nearz) != 0) {  // (skipped by the wavefront when no lane is near)
                 // a plane within the margin: has the reference crossed it before the exit event?  Axis j's events
                 // sort before the exit event of axis k on ties iff j < k.
@@ -619,9 +625,9 @@ struct CellRay {
                 const bool  bz = ttz < tk;
                 const int sx = f2i_small(i0x) - lnx - (bx ? 0 : 1), sy = f2i_small(i0y) - lny - (by ? 0 : 1),
                           sz = f2i_small(i0z) - lnz - (bz ? 0 : 1);
-                wx = nearx ? min(max(sx, ox), fwx) : wx;
-                wy = neary ? min(max(sy, oy), fwy) : wy;
-                wz = nearz ? min(max(sz, oz), fwz) : wz;
+                wx = nearx ? clamp_ordered(sx, ox, fwx) : wx;
+                wy = neary ? clamp_ordered(sy, oy, fwy) : wy;
+                wz = nearz ? clamp_ordered(sz, oz, fwz) : wz;
             }
             // the voxel just entered is tested even when it lies outside the loaded area; the ray
             // ends after that test (raytrace.glsl:52 comes before the next :43).  Only the exit axis can have
@@ -644,9 +650,9 @@ struct CellRay {
 #ifdef VRT_DIAG_SEC_UTIL
                 dB2 += i;
 #endif
-                const float tx = ((float)(wx + ln1x) - rnx) * inx;
-                const float ty = ((float)(wy + ln1y) - rny) * iny;
-                const float tz = ((float)(wz + ln1z) - rnz) * inz;
+                const float tx = (plane_float(wx + ln1x) - rnx) * inx;
+                const float ty = (plane_float(wy + ln1y) - rny) * iny;
+                const float tz = (plane_float(wz + ln1z) - rnz) * inz;
                 const bool  cy = ty < tx, cz = tz < __builtin_fminf(tx, ty);  // util.glsl:28-42, as in phase A
                 const bool  kx = !cy && !cz, ky = cy && !cz;
                 k = cz ? 2 : (cy ? 1 : 0);

@@ -201,14 +201,14 @@ def main():
     ap.add_argument("--shard", choices=["poses", "strips"], default="poses",
                     help="poses (the headline job): one frame of its own pose per rank, weak scaling; strips: ONE frame "
                          "dealt to the ranks in interleaved 16-row strips, gathered and put back in row order on rank 0")
-    ap.add_argument("--gather-every", type=int, default=4,
+    ap.add_argument("--gather-every", type=int, default=8,
                     help="frames per gather (pose sharding, N > 1): each rank fills a buffer of this many frames and hands it "
                          "to one gather, which overlaps the tracing of the next buffer; every frame still reaches rank 0 "
                          "inside the timed region.  1 = one gather per frame")
-    ap.add_argument("--gather-pixels", choices=["bgr", "bgra"], default="bgr",
+    ap.add_argument("--gather-pixels", choices=["bgr", "bgr_pack", "bgra"], default="bgr",
                     help="what crosses the links of a gather (pose- or strip-sharded): bgr = three bytes per pixel (the alpha byte, 255 on "
-                         "every path of the shader, is dropped by a pack kernel before the send and restored on rank 0 after "
-                         "it); bgra = the frames as they are")
+                         "every path of the shader, is not written by the trace kernel -- vrt_outputs.bgr8 -- and restored on rank 0 "
+                         "after the gather); bgr_pack = the same bytes made by a pack kernel behind a BGRA8 trace; bgra = the frames as they are")
     ap.add_argument("--overlap", type=int, default=2,
                     help="streams the context deals its frames to (vrt_set_frame_overlap): 2 lets the end of one frame's "
                          "launch run under the beginning of the next; 1 = every launch behind the one before.  A strip-sharded "
@@ -280,6 +280,12 @@ def main():
     overlap = 1 if (multi and strips) else max(1, min(4, args.overlap))
     stream = torch.cuda.ExternalStream(core.stream(), device=torch.device("cuda", local_rank))
     host = args.backend == "gloo"
+    # The context's stream is torch's current stream from here on: the collectives and the waits of a step are enqueued on
+    # it without entering a stream context per step (6.7 us of host time each, measured: tools/host_cost_probe.py -- with
+    # a gather per four frames the host side of a step was 42 us against 36 us of GPU work).
+    import contextlib
+    torch.cuda.set_stream(stream)
+    on_stream = contextlib.nullcontext
     # frame buffers: two (the gather of frame k overlaps the trace of frame k+1), and one per stream when more than
     # two frames are in flight, so that no two launches in flight write one buffer
     frames = [torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(max(2, overlap))]
@@ -288,7 +294,9 @@ def main():
     G = max(1, args.gather_every)
     gathered = [None, None]
     batch = batch3 = arrived = None
-    bgr = args.gather_pixels == "bgr"
+    bgr = args.gather_pixels != "bgra"
+    pack = args.gather_pixels == "bgr_pack"   # BGRA8 frames packed by a kernel of their own behind the trace (A/B runs); default: the
+                                              # trace kernel writes the three-byte plane itself
     C_SENT = 3 if bgr else 4            # bytes per pixel on the link
     if multi and not strips:
         batch = [torch.zeros((G, H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
@@ -324,15 +332,27 @@ def main():
 
     counter = [0]
 
+    # every launch of the timed loop with its arguments converted once (GraphicsCore.bound_trace_device)
+    bound = {}
+    if strips:
+        for b in range(2):
+            key = "bgr8" if (bgr and not pack) else "bgra8"
+            dst = packed3[b] if key == "bgr8" else packed[b]
+            bound[b] = core.bound_trace_strips_device(cam, W, H, STRIP_H, rank, world, {key: dst.data_ptr()})
+    elif multi:
+        for b in range(2):
+            for j in range(G):
+                dst = {"bgr8": batch3[b][j].data_ptr()} if (bgr and not pack) else {"bgra8": batch[b][j].data_ptr()}
+                bound[(b, j)] = core.bound_trace_device(cam, W, H, 0, H, dst)
+    else:
+        for i, f in enumerate(frames):
+            bound[i] = core.bound_trace_device(cam, W, H, 0, H, {"bgra8": f.data_ptr()})
+
     def step():
         b = counter[0] & 1
         counter[0] += 1
         if strips and host:
-            core.trace_strips_device(cam, W, H, STRIP_H, rank, world, {"bgra8": packed[b].data_ptr()})
-            send = packed[b]
-            if bgr:
-                core.pack_bgr(packed[b].data_ptr(), packed3[b].data_ptr(), pad_rows * W)
-                send = packed3[b]
+            send = trace_strip_part(b)
             core.sync()
             cpu_parts = [torch.empty((pad_rows, W, C_SENT), dtype=torch.uint8) for _ in range(world)] if rank == 0 else None
             dist.gather(send.cpu(), cpu_parts, dst=0)
@@ -341,15 +361,11 @@ def main():
                 torch.cuda.synchronize()
                 assemble(b)
         elif strips:
-            with torch.cuda.stream(stream):
+            with on_stream():
                 if pending[b] is not None:
                     pending[b].wait()
-                core.trace_strips_device(cam, W, H, STRIP_H, rank, world, {"bgra8": packed[b].data_ptr()})
+                send = trace_strip_part(b)
                 if multi:
-                    send = packed[b]
-                    if bgr:   # the pack kernel runs on the context's stream, behind the trace
-                        core.pack_bgr(packed[b].data_ptr(), packed3[b].data_ptr(), pad_rows * W)
-                        send = packed3[b]
                     pending[b] = dist.gather(send, list(parts_buf[b].unbind(0)) if rank == 0 else None, dst=0, async_op=True)
                     if rank == 0:
                         pending[b].wait()            # orders the copy below behind the gather on this stream
@@ -357,16 +373,26 @@ def main():
                         assemble(b)
         elif multi:
             b, j = fill["buf"], fill["n"]
-            with torch.cuda.stream(stream):
+            with on_stream():
                 if j == 0:
                     landed(b)                        # the traces below may overwrite batch[b] only after its gather
                     core.fork()                      # ... on whichever of the context's streams they run
-                core.trace_device(cam, W, H, 0, H, {"bgra8": batch[b][j].data_ptr()})
+                bound[(b, j)]()
             fill["n"], fill["last"] = j + 1, (b, j)
             if fill["n"] == G:
                 flush()
         else:
-            core.trace_device(cam, W, H, 0, H, {"bgra8": frames[(counter[0] - 1) % len(frames)].data_ptr()})
+            bound[(counter[0] - 1) % len(frames)]()
+
+    def trace_strip_part(b):
+        """This rank's strips of the frame into buffer b, as they will travel: returns the tensor to send."""
+        bound[b]()
+        if bgr and not pack:
+            return packed3[b]
+        if pack:   # the pack kernel runs on the context's stream, behind the trace
+            core.pack_bgr(packed[b].data_ptr(), packed3[b].data_ptr(), pad_rows * W)
+            return packed3[b]
+        return packed[b]
 
     def assemble(b):
         """Rank 0, strips: the gathered parts of buffer b back in image order (and, if they travelled without it, with
@@ -399,10 +425,9 @@ def main():
         b = fill["buf"]
         if batch is None or fill["n"] == 0:
             return
-        send = batch[b]
-        if bgr:
+        send = batch3[b] if bgr else batch[b]
+        if pack:
             core.pack_bgr(batch[b].data_ptr(), batch3[b].data_ptr(), G * H * W)   # on the context's stream, behind the traces (it joins them)
-            send = batch3[b]
         else:
             core.join()                              # the context's stream waits for the traces on its other streams
         if host:
@@ -410,7 +435,7 @@ def main():
             dist.gather(send.cpu(), gathered[b], dst=0)
             pending[b] = True
         else:
-            with torch.cuda.stream(stream):
+            with on_stream():
                 # RCCL gather to rank 0, ordered behind the traces (and the pack) on the context's stream
                 pending[b] = dist.gather(send, gathered[b], dst=0, async_op=True)
         fill["buf"], fill["n"] = b ^ 1, 0
@@ -420,10 +445,10 @@ def main():
         for b in range(2):
             if pending[b] is not None:
                 if batch is not None:
-                    with torch.cuda.stream(stream):
+                    with on_stream():
                         landed(b)
                 else:
-                    with torch.cuda.stream(stream):
+                    with on_stream():
                         pending[b].wait()
                     pending[b] = None
         core.sync()
@@ -445,12 +470,14 @@ def main():
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
+        enqueue_s.append(time.perf_counter() - t0)   # host time to enqueue the region's work (no wait in it unless a queue is full)
         fence()
         return time.perf_counter() - t0
 
     # A region of a few milliseconds is at the mercy of one slow wake-up from its closing wait: such a run times the
     # region three times (each one the same --steps steps between the same fences) and reports the median, with all
     # three in `region_ms`.  The decision is taken on the first region's time and agreed between the ranks.
+    enqueue_s = []
     regions = [timed_region()]
     again = torch.tensor([1.0 if regions[0] < 20e-3 else 0.0], dtype=torch.float64, device="cpu" if host else "cuda")
     if multi:
@@ -568,6 +595,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            "host_enqueue_ms_per_step": sorted(enqueue_s)[len(enqueue_s) // 2] / args.steps * 1e3,   # this rank's host side of a step
             "region_ms": [r * 1e3 for r in regions],   # every timed region (each: --steps steps between two fences); value and ms_per_step are the median's
             # the same job without the framebuffer gather: every rank's frame / the slowest rank's kernel
             "value_without_gather": rays / args.steps / kern_max_s / 1e6,
@@ -595,7 +623,11 @@ def main():
             fx = json.load(open(gold))
             if np.array_equal(np.asarray(fx["cam_col_major_bits"], np.uint32), np.asarray(cam, np.float32).view(np.uint32)):
                 last_frame = frames[(counter[0] - 1) & 1] if strips else frames[(counter[0] - 1) % len(frames)]
-                last = (batch[fill["last"][0]][fill["last"][1]] if batch is not None else last_frame).cpu().numpy()
+                if batch is not None and bgr and not pack:   # traced as three-byte pixels: the frame as rank 0 holds it after the gather
+                    last_frame = arrived[fill["last"][0]][0][fill["last"][1]]
+                elif batch is not None:
+                    last_frame = batch[fill["last"][0]][fill["last"][1]]
+                last = last_frame.cpu().numpy()
                 line["parity"] = {"bgra8_sha256_equals_oracle_golden": hashlib.sha256(last.tobytes()).hexdigest() == fx["sha256"]["bgra8"],
                                   "steps_sum_equals_oracle_golden": sum_steps == fx["totals"]["steps"] if not strips else None}
         if world == 1 and not args.no_cpu_baseline:

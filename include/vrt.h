@@ -73,6 +73,10 @@ typedef struct vrt_outputs {
     float    *t;            /* t_distances[next_xyz] at the hit; -1 on a miss */
     float    *hit_point;    /* 3 per pixel; zeros on a miss */
     float    *rgba;         /* 4 per pixel, the shader's colour before the UNORM store */
+    uint8_t  *bgr8;         /* 3 B/pixel, byte order B,G,R: the bgra8 pixel without its alpha byte, which is 255 on every path of
+                               the shader (render.comp:9-13) -- the frame as it travels between GPUs, written by the trace
+                               kernel itself instead of by vrt_pack_bgr behind it.  A caller built against the struct
+                               without this member passes the smaller struct_size and is served as before. */
 } vrt_outputs;
 
 /* Measurement knobs, read from the environment once per vrt_create and meant for A/B runs only (none changes a

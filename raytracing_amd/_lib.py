@@ -36,7 +36,7 @@ class VrtConfig(C.Structure):
 class VrtOutputs(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("memory", C.c_uint32), ("bgra8", C.c_void_p), ("voxel", C.c_void_p),
                 ("face", C.c_void_p), ("steps", C.c_void_p), ("t", C.c_void_p), ("hit_point", C.c_void_p),
-                ("rgba", C.c_void_p)]
+                ("rgba", C.c_void_p), ("bgr8", C.c_void_p)]
 
 
 class VrtSecondaryOutputs(C.Structure):

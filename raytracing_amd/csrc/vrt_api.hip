@@ -503,10 +503,24 @@ int ensure_stage(vrt_ctx *c, size_t total)
     return VRT_OK;
 }
 
-int do_trace(vrt_ctx *c, const float *cam, uint32_t w, uint32_t h, const vrt::RowMap &rows, const vrt_outputs *out)
+// vrt_outputs as a caller of either layout passed it: the struct grew by `bgr8` at its end, and a caller built against
+// the older header says so with its struct_size.
+constexpr uint32_t kOutputsSizeV1 = (uint32_t)offsetof(vrt_outputs, bgr8);
+int read_outputs(const vrt_outputs *in, vrt_outputs &o)
 {
-    if (!c || !cam || !out) return fail(VRT_E_INVALID_ARG, "null argument");
-    if (out->struct_size != sizeof(vrt_outputs)) return fail(VRT_E_INVALID_ARG, "vrt_outputs.struct_size mismatch");
+    if (in->struct_size != sizeof(vrt_outputs) && in->struct_size != kOutputsSizeV1)
+        return fail(VRT_E_INVALID_ARG, "vrt_outputs.struct_size mismatch");
+    o = vrt_outputs{};
+    std::memcpy(&o, in, in->struct_size);
+    return VRT_OK;
+}
+
+int do_trace(vrt_ctx *c, const float *cam, uint32_t w, uint32_t h, const vrt::RowMap &rows, const vrt_outputs *given)
+{
+    if (!c || !cam || !given) return fail(VRT_E_INVALID_ARG, "null argument");
+    vrt_outputs view;
+    { int rc = read_outputs(given, view); if (rc != VRT_OK) return rc; }
+    const vrt_outputs *out = &view;
     if (out->memory != VRT_MEM_HOST && out->memory != VRT_MEM_DEVICE) return fail(VRT_E_INVALID_ARG, "bad outputs.memory");
     vrt::TraceParams p;
     bool use_skip = false;
@@ -516,21 +530,22 @@ int do_trace(vrt_ctx *c, const float *cam, uint32_t w, uint32_t h, const vrt::Ro
     { int rc = prepare_trace(c, S, st, true, cam, w, h, rows, false, p, use_skip); if (rc != VRT_OK) return rc; }
 
     const size_t px = (size_t)rows.rows * w;
-    Plane planes[7] = {{0, out->bgra8 ? px * 4 : 0, out->bgra8},       {0, out->voxel ? px * 12 : 0, out->voxel},
-                       {0, out->face ? px * 4 : 0, out->face},         {0, out->steps ? px * 4 : 0, out->steps},
-                       {0, out->t ? px * 4 : 0, out->t},               {0, out->hit_point ? px * 12 : 0, out->hit_point},
-                       {0, out->rgba ? px * 16 : 0, out->rgba}};
-    void *dev[7];
+    constexpr int kPlanes = 8;
+    Plane planes[kPlanes] = {{0, out->bgra8 ? px * 4 : 0, out->bgra8},       {0, out->voxel ? px * 12 : 0, out->voxel},
+                             {0, out->face ? px * 4 : 0, out->face},         {0, out->steps ? px * 4 : 0, out->steps},
+                             {0, out->t ? px * 4 : 0, out->t},               {0, out->hit_point ? px * 12 : 0, out->hit_point},
+                             {0, out->rgba ? px * 16 : 0, out->rgba},        {0, out->bgr8 ? px * 3 : 0, out->bgr8}};
+    void *dev[kPlanes];
     if (out->memory == VRT_MEM_DEVICE) {
-        for (int i = 0; i < 7; ++i) dev[i] = planes[i].host;
+        for (int i = 0; i < kPlanes; ++i) dev[i] = planes[i].host;
     } else {
         size_t total = 0;
-        for (int i = 0; i < 7; ++i) { planes[i].off = total; total += (planes[i].bytes + 255) & ~(size_t)255; }
+        for (int i = 0; i < kPlanes; ++i) { planes[i].off = total; total += (planes[i].bytes + 255) & ~(size_t)255; }
         { int rc = ensure_stage(c, total); if (rc != VRT_OK) return rc; }
-        for (int i = 0; i < 7; ++i) dev[i] = planes[i].bytes ? (char *)c->d_stage + planes[i].off : nullptr;
+        for (int i = 0; i < kPlanes; ++i) dev[i] = planes[i].bytes ? (char *)c->d_stage + planes[i].off : nullptr;
     }
     p.bgra8 = (uint8_t *)dev[0]; p.voxel = (int32_t *)dev[1]; p.face = (int32_t *)dev[2]; p.steps = (uint32_t *)dev[3];
-    p.t = (float *)dev[4]; p.hit_point = (float *)dev[5]; p.rgba = (float *)dev[6];
+    p.t = (float *)dev[4]; p.hit_point = (float *)dev[5]; p.rgba = (float *)dev[6]; p.bgr8 = (uint8_t *)dev[7];
 
     const bool timed = c->time_every != 0 && c->launch_seq++ % c->time_every == 0;
     if (timed && c->ev_pending == kEventRing) { int rc = drain_events(c); if (rc != VRT_OK) return rc; }
@@ -544,7 +559,7 @@ int do_trace(vrt_ctx *c, const float *cam, uint32_t w, uint32_t h, const vrt::Ro
     if (lane) c->lane_busy[lane] = true;
 
     if (out->memory == VRT_MEM_HOST) {  // (lane 0: its stream)
-        for (int i = 0; i < 7; ++i)
+        for (int i = 0; i < kPlanes; ++i)
             if (planes[i].bytes) HIP_TRY(hipMemcpyAsync(planes[i].host, dev[i], planes[i].bytes, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
@@ -733,10 +748,12 @@ int vrt_trace(vrt_ctx *c, const float cam[16], uint32_t w, uint32_t h, uint32_t 
     return do_trace(c, cam, w, h, rows, out);
 }
 
-int vrt_trace_static(vrt_ctx *c, const float cam[16], uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, const vrt_outputs *out)
+int vrt_trace_static(vrt_ctx *c, const float cam[16], uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, const vrt_outputs *given)
 {
-    if (!c || !cam || !out) return fail(VRT_E_INVALID_ARG, "null argument");
-    if (out->struct_size != sizeof(vrt_outputs)) return fail(VRT_E_INVALID_ARG, "vrt_outputs.struct_size mismatch");
+    if (!c || !cam || !given) return fail(VRT_E_INVALID_ARG, "null argument");
+    vrt_outputs view;
+    { int rc = read_outputs(given, view); if (rc != VRT_OK) return rc; }
+    const vrt_outputs *out = &view;
     if (out->memory != VRT_MEM_DEVICE)
         return fail(VRT_E_INVALID_ARG, "vrt_trace_static writes DEVICE planes only (host planes need a staging buffer)");
     if (y0 > y1 || y1 > h) return fail(VRT_E_INVALID_ARG, "row band [%u,%u) outside the frame", y0, y1);
@@ -764,7 +781,7 @@ int vrt_trace_static(vrt_ctx *c, const float cam[16], uint32_t w, uint32_t h, ui
     bool use_skip = false;
     { int rc = prepare_trace(c, *S, c->stream, false, cam, w, h, rows, false, p, use_skip); if (rc != VRT_OK) return rc; }
     p.bgra8 = out->bgra8; p.voxel = out->voxel; p.face = out->face; p.steps = out->steps;
-    p.t = out->t; p.hit_point = out->hit_point; p.rgba = out->rgba;
+    p.t = out->t; p.hit_point = out->hit_point; p.rgba = out->rgba; p.bgr8 = out->bgr8;
     if (use_skip) { int rc = attach_row_sched(c, *S, p, 1); if (rc != VRT_OK) return rc; }
     if (use_skip) { HIP_TRY(vrt::launch_trace_skip(p, c->voxel_bytes, c->stream)); c->last_kernel = "skip"; }
     else          { HIP_TRY(vrt::launch_trace_literal(p, c->voxel_bytes, c->stream)); c->last_kernel = "literal"; }

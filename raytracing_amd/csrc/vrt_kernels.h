@@ -98,6 +98,7 @@ struct TraceParams {
     float    *t;
     float    *hit_point;
     float    *rgba;
+    uint8_t  *bgr8;   // three bytes per pixel: the bgra8 pixel without its alpha byte
 };
 
 // traversal kernels

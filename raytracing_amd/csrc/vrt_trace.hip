@@ -1033,6 +1033,7 @@ VRT_DEV void finish_pixel(const PARAMS &P, unsigned gx, unsigned gy, size_t i, c
     if (cross) px = 0xffff4d4du;
 
     if (P.bgra8) ((unsigned *)P.bgra8)[i] = px;
+    if (P.bgr8) { uint8_t *d = P.bgr8 + 3 * i; d[0] = (uint8_t)px; d[1] = (uint8_t)(px >> 8); d[2] = (uint8_t)(px >> 16); }
     if (P.voxel) { P.voxel[3 * i] = H.vx; P.voxel[3 * i + 1] = H.vy; P.voxel[3 * i + 2] = H.vz; }
     if (P.face) P.face[i] = H.hit ? 2 * H.k + (H.sk < 0 ? 1 : 0) : (H.capped ? -2 : -1);
 #ifdef VRT_DIAG_ITERS

@@ -229,6 +229,7 @@ impl GraphicsCore {
             t: null_mut(),
             hit_point: null_mut(),
             rgba: null_mut(),
+            bgr8: null_mut(),
         };
         // nalgebra's Matrix4<f32> is column major: as_slice() is the 16 floats the library takes
         check(unsafe {

@@ -33,6 +33,7 @@ pub struct VrtOutputs {
     pub t: *mut f32,
     pub hit_point: *mut f32,
     pub rgba: *mut f32,
+    pub bgr8: *mut u8,
 }
 
 #[repr(C)]

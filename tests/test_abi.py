@@ -36,7 +36,7 @@ def test_version_and_error_strings():
 
 def test_struct_sizes_match_header_layout():
     assert C.sizeof(L.VrtConfig) == 24
-    assert C.sizeof(L.VrtOutputs) == 8 + 7 * C.sizeof(C.c_void_p)
+    assert C.sizeof(L.VrtOutputs) == 8 + 8 * C.sizeof(C.c_void_p)
 
 
 def test_argument_validation_without_a_device():

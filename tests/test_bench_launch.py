@@ -43,12 +43,13 @@ def test_two_ranks_on_one_gpu_over_gloo_print_one_line(pixels, steps):
     plainly, with both ranks sharing the one GPU of the box and the gather going through host memory.  Rank 0 checks
     the last frame that arrived from every rank against that rank's pose traced by itself."""
     p = run_bench("--gpus", "2", "--backend", "gloo", "--steps", steps, "--warmup", "1", "--no-cpu-baseline", "--probe", "16",
-                  "--gather-pixels", pixels)
+                  "--gather-pixels", pixels, "--gather-every", "4")
     assert p.returncode == 0, p.stderr[-3000:]
     lines = json_lines(p.stdout)
     assert len(lines) == 1, p.stdout
     assert lines[0]["n_gpus"] == 2 and lines[0]["steps"] == int(steps) and lines[0]["value"] > 0
     assert lines[0]["scaling"] == "weak" and lines[0]["roofline"]["timed_launches"] >= 16
+    assert lines[0]["host_enqueue_ms_per_step"] > 0
     assert lines[0]["gather"] == {"bytes_per_pixel_on_the_link": 3 if pixels == "bgr" else 4, "frames_per_gather": 4,
                                   "last_frame_of_every_rank_equals_its_trace": True}
 

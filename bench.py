@@ -209,6 +209,10 @@ def main():
                     help="what crosses the links of a gather (pose- or strip-sharded): bgr = three bytes per pixel (the alpha byte, 255 on "
                          "every path of the shader, is not written by the trace kernel -- vrt_outputs.bgr8 -- and restored on rank 0 "
                          "after the gather); bgr_pack = the same bytes made by a pack kernel behind a BGRA8 trace; bgra = the frames as they are")
+    ap.add_argument("--settle-ms", type=float, default=30.0,
+                    help="untimed launches of the same frame for this long before the warm-up steps: the chip raises its clock over "
+                         "some ten milliseconds of load, and a region of 20 steps (0.8 ms) measured right after set-up runs 12-15 %% "
+                         "slower than the same region a few regions later (0: none)")
     ap.add_argument("--overlap", type=int, default=2,
                     help="streams the context deals its frames to (vrt_set_frame_overlap): 2 lets the end of one frame's "
                          "launch run under the beginning of the next; 1 = every launch behind the one before.  A strip-sharded "
@@ -458,6 +462,14 @@ def main():
             torch.cuda.synchronize()
 
     core.set_frame_overlap(overlap)
+    # the clock: untimed launches of this rank's frame until the chip holds its sustained clock (see --settle-ms); then the
+    # warm-up steps proper, which also fill the gather's buffers
+    settle = [core.bound_trace_device(cam, W, H, 0, H, {"bgra8": f.data_ptr()}) for f in frames[:2]]
+    t_settle = time.perf_counter()
+    while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+        for i in range(16):
+            settle[i & 1]()
+        core.sync()
     for _ in range(args.warmup):
         step()
     fence()
@@ -595,6 +607,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            "settle_ms": args.settle_ms,   # untimed launches before the warm-up steps (clock ramp), see --settle-ms
             "host_enqueue_ms_per_step": sorted(enqueue_s)[len(enqueue_s) // 2] / args.steps * 1e3,   # this rank's host side of a step
             "region_ms": [r * 1e3 for r in regions],   # every timed region (each: --steps steps between two fences); value and ms_per_step are the median's
             # the same job without the framebuffer gather: every rank's frame / the slowest rank's kernel

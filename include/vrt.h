@@ -265,8 +265,10 @@ int vrt_download_world(vrt_ctx *ctx, void *block_out, uint32_t memory);
 
 /* Copy the traversal index out (tests of its builders; the reference has no such structure): `cells_out`, (n/4)^3
  * records of 16 bytes -- the 64-bit occupancy mask of a 4^3 cell, bit z*16 + y*4 + x, then its eight octant
- * distances -- and `pyr_out`, (n/4)^3 x 16 bytes of column-top pyramid entries as levelled for the window of the
- * last trace (VRT_E_UNSUPPORTED before the first trace after a world change); either may be NULL.  The index is
+ * distances -- and `pyr_out`, (n/4)^3 x 64 bytes: per cell eight 64-bit words of column-top entries (word = ray
+ * descends | travels towards -x << 1 | towards -z << 2; four 16-bit entries per word, one per voxel level of the cell)
+ * as levelled for the window of the last trace (VRT_E_UNSUPPORTED before the first trace after a world change);
+ * either may be NULL.  The index is
  * brought up to date with the voxel image first, as vrt_reset_distance_field does. */
 int vrt_download_index(vrt_ctx *ctx, void *cells_out, void *pyr_out, uint32_t memory);
 

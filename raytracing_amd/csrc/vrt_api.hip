@@ -150,10 +150,10 @@ struct vrt_ctx {
     bool        dist_nonzero = false;
     bool        have_world   = false;
     // skip structure
-    uint4      *d_cells      = nullptr;  // (n/4)^3 x 32 B: per cell the record (occupancy mask + octant distances), then its pyramid words
-    uint16_t   *d_tops       = nullptr;  // column-top pyramid scratch, 2 * (n/4)^2
-    uint4      *d_pyr        = nullptr;  // d_cells + 1: column-top pyramid at voxel precision, cell i's words at d_pyr[2 * i]
-    uint8_t    *d_build      = nullptr;  // 6 x (n/4)^3 B: the x and y planes of the octant distance transform, kept between builds
+    uint4      *d_cells      = nullptr;  // (n/4)^3 x 128 B: per cell the record (occupancy mask + octant distances), then its column-top words
+    uint16_t   *d_tops       = nullptr;  // column-top tables (build scratch), TOPS_LEVELS * (n/4)^2
+    uint4      *d_pyr        = nullptr;  // d_cells + 1: column-top words at voxel precision, cell i's from d_pyr[CELL_U4 * i]
+    uint8_t    *d_build      = nullptr;  // 14 x (n/4)^3 B: the cells' masks side by side and the x and y planes of the octant distance transform, kept between builds
     // what the skip structure has not seen yet: nothing (skip_valid), a box of regenerated chunks, or everything
     bool        index_built  = false;    // records and planes describe some earlier state of the whole voxel image
     bool        dirty_box    = false;    // chunks inside [dirty_lo, dirty_hi) (world cells of 4^3 voxels) changed since
@@ -267,9 +267,9 @@ int ensure_skip_structure(vrt_ctx *c, int offcy)
     const bool work = !c->skip_valid || (offcy >= 0 && c->pyr_offcy != offcy);
     if (work) { int rc = join_lanes(c); if (rc != VRT_OK) return rc; }  // no trace reads the index while it is rewritten
     if (!c->skip_valid) {
-        if (!c->d_cells) { HIP_TRY(hipMalloc(&c->d_cells, cells(c) * 2 * sizeof(uint4))); c->d_pyr = c->d_cells + 1; }
-        if (!c->d_tops) HIP_TRY(hipMalloc(&c->d_tops, 2 * (size_t)(c->n / 4) * (c->n / 4) * sizeof(uint16_t)));
-        if (!c->d_build) HIP_TRY(hipMalloc(&c->d_build, 6 * cells(c)));
+        if (!c->d_cells) { HIP_TRY(hipMalloc(&c->d_cells, cells(c) * vrt::CELL_U4 * sizeof(uint4))); c->d_pyr = c->d_cells + 1; }
+        if (!c->d_tops) HIP_TRY(hipMalloc(&c->d_tops, (size_t)vrt::TOPS_LEVELS * (c->n / 4) * (c->n / 4) * sizeof(uint16_t)));
+        if (!c->d_build) HIP_TRY(hipMalloc(&c->d_build, vrt::PLANE_BYTES_PER_CELL * cells(c)));
         const int nc = (int)c->n / 4;
         if (c->index_built && c->dirty_box) {
             // only regenerated chunks since the last build: their cells, and the cells whose distances see them
@@ -291,7 +291,7 @@ int ensure_skip_structure(vrt_ctx *c, int offcy)
         c->pyr_offcy = -1;
     }
     if (offcy >= 0 && c->pyr_offcy != offcy) {
-        HIP_TRY(vrt::launch_build_voxel_pyramid(c->d_cells, (int)c->n / 4, offcy, c->d_tops, c->d_pyr, c->stream));
+        HIP_TRY(vrt::launch_build_voxel_pyramid(c->d_build, (int)c->n / 4, offcy, c->d_tops, c->d_pyr, c->stream));
         c->pyr_offcy = offcy;
     }
     if (work) return fork_lanes(c);
@@ -1010,15 +1010,18 @@ int vrt_download_index(vrt_ctx *c, void *cells_out, void *pyr_out, uint32_t memo
     HIP_TRY(hipSetDevice(c->device));
     { int rc = ensure_skip_structure(c, -1); if (rc != VRT_OK) return rc; }
     if (pyr_out && c->pyr_offcy < 0) return fail(VRT_E_UNSUPPORTED, "the column-top pyramid is levelled by the first trace after a world change");
-    // 16 of every 32 bytes each: gathered by a kernel, into the caller's device memory or into a staging buffer
+    // 16 (the record) and 64 (the column-top words) of every 128 bytes: gathered by a kernel, into the caller's device
+    // memory or into a staging buffer
     void *stage = nullptr;
-    if (memory == VRT_MEM_HOST) HIP_TRY(hipMalloc(&stage, cells(c) * sizeof(uint4)));
+    if (memory == VRT_MEM_HOST) HIP_TRY(hipMalloc(&stage, cells(c) * vrt::PYR_U4 * sizeof(uint4)));
     const uint4 *src[2] = {c->d_cells, c->d_pyr};
+    const unsigned part[2] = {1u, vrt::PYR_U4};
     void *dst[2] = {cells_out, pyr_out};
     for (int i = 0; i < 2; ++i) {
         if (!dst[i]) continue;
-        hipError_t e = vrt::launch_copy_every_other(src[i], static_cast<uint4 *>(stage ? stage : dst[i]), cells(c), c->stream);
-        if (e == hipSuccess && stage) e = hipMemcpyAsync(dst[i], stage, cells(c) * sizeof(uint4), hipMemcpyDeviceToHost, c->stream);
+        const size_t bytes = cells(c) * part[i] * sizeof(uint4);
+        hipError_t e = vrt::launch_copy_cell_part(src[i], static_cast<uint4 *>(stage ? stage : dst[i]), cells(c), part[i], c->stream);
+        if (e == hipSuccess && stage) e = hipMemcpyAsync(dst[i], stage, bytes, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess && stage) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) { if (stage) (void)hipFree(stage); HIP_TRY(e); }
     }

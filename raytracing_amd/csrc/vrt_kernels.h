@@ -12,6 +12,13 @@
 
 namespace vrt {
 
+// One cell of the skip structure (TraceParams::cells): a 128-byte line
+constexpr unsigned CELL_U4 = 8;     // uint4 units per cell
+constexpr unsigned CELL_SHIFT = 7;  // log2 of its bytes
+constexpr unsigned PYR_U4 = 4;      // uint4 units of column-top words per cell, from cells[CELL_U4 * i + 1]
+constexpr unsigned PLANE_BYTES_PER_CELL = 14;  // launch_build_cells' planes: masks 8, x planes 2, y planes 4
+constexpr int      TOPS_LEVELS = 9; // tables of column tops: squares of 1, 2, .. 256 cell columns
+
 // Records the thread's error message (vrt_last_error) and returns `code`; shared by the files of the C ABI.
 int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 
@@ -67,21 +74,23 @@ struct TraceParams {
     // world
     const void     *block;  // n^3 texels (u8 or u16), linear x fastest
     const uint16_t *dist;   // n^3 texels or nullptr (all zero)
-    // skip structure: 32 bytes per cell of 4^3 voxels (torus space, linear order): the 16-byte record of cell i at
-    // cells[2 * i], its column-top pyramid words behind it at pyr[2 * i], pyr = cells + 1
+    // skip structure: CELL_BYTES (128) bytes per cell of 4^3 voxels (torus space, linear order), one cache line: the
+    // 16-byte record of cell i at cells[CELL_U4 * i], its eight column-top words behind it (bytes 16..79), the rest unused
     //   .x,.y  64-bit occupancy mask, bit = (z&3)*16 + (y&3)*4 + (x&3); zero for an empty cell
     //   .z,.w  eight octant distances, byte o = sx | sy<<1 | sz<<2 (bit set = positive direction):
     //          side of the largest empty cube of cells that starts at the cell and extends into
     //          that octant; 0 = the cell is non-empty, cap 32
     const uint4 *cells;
     int32_t  nc;                // n / 4
-    // column-top pyramid at voxel precision, two 64-bit words per cell (any cell, empty or not): for
-    // each of the cell's four voxel levels j a 16-bit entry (L + 1) << 12 | drop -- the aligned block of
-    // 2^L x 2^L cell columns around the cell holds no voxel at or above window level (4*layer + j) - drop
-    // (drop capped at 4095); 0 = not even the cell's own column qualifies.  Window levels are counted from
-    // the bottom of the loaded window, so the pyramid is rebuilt when the window's vertical offset changes.  .x,.y: the widest such block
-    // (read by rays that rise); .z,.w: the block the builder prefers for rays that descend.
-    const uint4 *pyr;
+    // column-top words at voxel precision, eight 64-bit words per cell (any cell, empty or not), word
+    // w = descending | negative x << 1 | negative z << 2 for the ray's direction of travel, at byte 16 + 8 * w of the
+    // cell: for each of the cell's four voxel levels j a 16-bit entry (L + 1) << 12 | drop -- the square of 2^L x 2^L cell
+    // columns that has the cell's own column at its corner and extends the way the ray travels (towards -x for a
+    // "negative x" word, ...) holds no voxel at or above window level (4*layer + j) - drop (drop capped at 4095);
+    // 0 = not even the cell's own column qualifies.  Window levels are counted from the bottom of the loaded window, so
+    // the words are rebuilt when the window's vertical offset changes.  Words of rays that rise hold the widest such
+    // square, words of rays that descend the square the builder prefers for them.
+    const uint4 *pyr;           // cells + 1
     // per-frame tables (device memory, filled by launch_frame_tables with the kernels' own arithmetic;
     // null = evaluate in place): the two divisions of raytrace.glsl:121 per column / per row, and the
     // sine of raytrace.glsl:131 for every voxel coordinate a hit point can floor to
@@ -116,18 +125,21 @@ hipError_t launch_terrain(void *block, int voxel_bytes, int n, int x0, int y0, i
                           int ex, int ey, int ez, hipStream_t s);
 // `count` chunks of 32^3 voxels at chunk positions xyz[3 * i ..] (host memory), 64 chunks per launch
 hipError_t launch_terrain_chunks(void *block, int voxel_bytes, int n, const int32_t *xyz, uint32_t count, hipStream_t s);
-// cells = nc^3 x 32 bytes (record, pyramid words); planes = 6 * nc^3 bytes: the x and y planes of the separable octant distance transform,
-// which must keep their contents between a build and the updates that follow it
+// cells = nc^3 x 128 bytes (record, column-top words); planes = PLANE_BYTES_PER_CELL * nc^3 bytes: the cells' occupancy masks side
+// by side and the x and y planes of the separable octant distance transform, which must keep their contents between a
+// build and the updates that follow it
 hipError_t launch_build_cells(const void *block, int voxel_bytes, int n, uint4 *cells, uint8_t *planes, hipStream_t s);
 // The same for the cells whose voxels changed, a box of the torus (origin in [0, nc), extent 1..nc per axis), and
 // for every cell around it whose distances depend on them.
 hipError_t launch_update_cells(const void *block, int voxel_bytes, int n, uint4 *cells, uint8_t *planes, const int origin[3],
                                const int extent[3], hipStream_t s);
-// tops: scratch of at least 2 * nc * nc uint16_t; offcy = rem_euclid(lower_y, n) / 4; pyr = cells + 1 (cell i's words at pyr[2 * i])
-hipError_t launch_build_voxel_pyramid(const uint4 *cells, int nc, int offcy, uint16_t *tops, uint4 *pyr, hipStream_t s);
+// planes: as launch_build_cells left them (the masks are read); tops: scratch of at least TOPS_LEVELS * nc * nc uint16_t; offcy = rem_euclid(lower_y, n) / 4; pyr = cells + 1 (cell i's words from pyr[CELL_U4 * i])
+hipError_t launch_build_voxel_pyramid(const uint8_t *planes, int nc, int offcy, uint16_t *tops, uint4 *pyr, hipStream_t s);
 hipError_t launch_frame_tables(float *ncx, float *ncy, float *sin2, uint32_t w, uint32_t h, float ncy_off,
                                const int32_t sin_base[3], uint32_t sin_len, hipStream_t s);
-hipError_t launch_copy_every_other(const uint4 *src, uint4 *dst, size_t count, hipStream_t s);  // dst[i] = src[2 * i]
+// dst[i * part + j] = src[CELL_U4 * i + j], j < part: the records (src = cells, part = 1) or the column-top words
+// (src = pyr, part = PYR_U4) out of the cells
+hipError_t launch_copy_cell_part(const uint4 *src, uint4 *dst, size_t count, unsigned part, hipStream_t s);
 hipError_t launch_any_nonzero_u16(const uint16_t *p, size_t count, uint32_t *flag, hipStream_t s);
 
 // Gathered strip buffers (parts x part_stride_rows packed rows of row_bytes each) -> frame of h rows.

@@ -264,7 +264,7 @@ VRT_DEV void traverse_skip(const TraceParams &P, float rox, float roy, float roz
         }
         const int cell = ((qz >> 2) * nc + (qy >> 2)) * nc + (qx >> 2);
         if (cell != cur_cell) {
-            const uint4 r = P.cells[2 * (size_t)cell];
+            const uint4 r = P.cells[CELL_U4 * (size_t)cell];
             cur_cell = cell;
             cur_mask = (uint64_t)r.x | ((uint64_t)r.y << 32);
             d        = (int)(((dhigh ? r.w : r.z) >> dshift) & 0xffu);
@@ -395,6 +395,7 @@ struct CellRay {
     float rnx, rny, rnz, dnx, dny, dnz, inx, iny, inz, thr0x, thr0y, thr0z;
     int   lnx, lny, lnz, ln1x, ln1y, ln1z, smx, smy, smz;  // (ln1 = ln + 1 + PLANE_BIAS, see plane_float)
     unsigned dsel;  // byte selector (v_perm_b32) of this ray's octant distance in the record's two distance words
+    unsigned psel;  // byte offset, in a cell, of the column-top word for this ray's direction of travel
     // state
     int      wx, wy, wz, w0, k, d, bit;
     unsigned pyr_lo, pyr_hi;  // the cell's word of the voxel-precision column-top pyramid
@@ -437,23 +438,23 @@ struct CellRay {
         uint4 r;
         uint2 pw;
         if (POW2) {
-            // (n <= 2048 in this form.)  The cell's coordinates are bit fields of the texel coordinates, which need no
+            // (n <= 1024 in this form.)  The cell's coordinates are bit fields of the texel coordinates, which need no
             // wrap of their own then (the field extraction drops the bits above the grid, off is a multiple of 4), and
-            // the byte offset of the cell's 32 bytes stays below 2^32: one 32-bit offset on the scalar base address,
-            // the pyramid word (rising: bytes 16..23, descending: 24..31) by the sign mask of the y direction.
+            // the byte offset of the cell's 128 bytes stays below 2^32: one 32-bit offset on the scalar base address,
+            // the column-top word of the ray's direction of travel at psel (16 .. 72) behind it.
             const unsigned L = (unsigned)P.nc_log2;
             const unsigned cx = __builtin_amdgcn_ubfe((unsigned)qx, 2u, L), cy = __builtin_amdgcn_ubfe((unsigned)qy, 2u, L),
                            cz = __builtin_amdgcn_ubfe((unsigned)qz, 2u, L);
-            const unsigned at = ((((cz << L) | cy) << L) | cx) << 5;
+            const unsigned at = ((((cz << L) | cy) << L) | cx) << CELL_SHIFT;
             const char *base = reinterpret_cast<const char *>(P.cells);
             r  = *reinterpret_cast<const uint4 *>(base + at);
-            pw = *reinterpret_cast<const uint2 *>(base + (at | ((unsigned)smy & 8u)) + 16);
+            pw = *reinterpret_cast<const uint2 *>(base + (at | psel));
         } else {
             qx -= qx >= n ? n : 0; qy -= qy >= n ? n : 0; qz -= qz >= n ? n : 0;
-            const unsigned cell = (unsigned)(((qz >> 2) * nc + (qy >> 2)) * nc + (qx >> 2));
-            const uint4 *rec = P.cells + 2u * cell;  // 32 bytes per cell: the record, then the pyramid words (2 * cell < 2^32)
-            r  = rec[0];
-            pw = reinterpret_cast<const uint2 *>(rec + 1)[smy & 1];  // rising: .x,.y
+            const size_t cell = (size_t)(unsigned)(((qz >> 2) * nc + (qy >> 2)) * nc + (qx >> 2));
+            const char *rec = reinterpret_cast<const char *>(P.cells) + (cell << CELL_SHIFT);  // the record, then the column-top words
+            r  = *reinterpret_cast<const uint4 *>(rec);
+            pw = *reinterpret_cast<const uint2 *>(rec + psel);
         }
         cur_mask = (uint64_t)r.x | ((uint64_t)r.y << 32);
         d        = (int)__builtin_amdgcn_perm(r.w, r.z, dsel);
@@ -499,6 +500,8 @@ struct CellRay {
         ln1x = lnx + 1 + PLANE_BIAS; ln1y = lny + 1 + PLANE_BIAS; ln1z = lnz + 1 + PLANE_BIAS;
         const int oct = (px ? 1 : 0) | (py ? 2 : 0) | (pz ? 4 : 0);
         dsel = 0x0c0c0c00u | (unsigned)oct;  // byte `oct` of {r.z, r.w}, zero extended
+        // word = descending | negative x << 1 | negative z << 2, eight bytes each, behind the 16-byte record
+        psel = 16u + ((unsigned)smy & 8u) + ((unsigned)smx & 16u) + ((unsigned)smz & 32u);
         // margin of the exit-point test, as 0.5 - VRT_MARGIN * (|pos| + |origin| + 1) = thr0 - VRT_MARGIN * |pos|
         thr0x = zx ? never : (CAMERA ? P.thr0[0] : 0.5f - VRT_MARGIN * (fabsf(rnx) + 1.0f));
         thr0y = zy ? never : (CAMERA ? P.thr0[1] : 0.5f - VRT_MARGIN * (fabsf(rny) + 1.0f));
@@ -562,22 +565,19 @@ struct CellRay {
             // ---- phase A: cross an empty box that holds the current voxel: the column-top block of the
             // voxel's level (also inside a non-empty cell, above its solid voxels) or the octant cube
             int fwx, fwy, fwz;  // last anchor of the box on each axis
-            // the entry's block is 2^L x 2^L cell columns, L + 1 = e >> 12: twice its side in cells against the cube's
+            // the entry's square is 2^L x 2^L cell columns, L + 1 = e >> 12: twice its side in cells against the cube's
             const int two = 1 << (e >> 12);
             if (FOLD > 0 && !boxed) {
                 fwx = wx; fwy = wy; fwz = wz;  // the voxel itself
-            } else if (e != 0 && two > d) {  // (measured: better than half and than twice that)
-                const int m4 = 2 * two - 1;  // voxels across the block, less one
-                // texel of the current anchor up to a multiple of n, which is a multiple of the block width
-                const int ux = (wx ^ smx) + P.off[0], uz = (wz ^ smz) + P.off[2];
-                fwx = m4 >= n - 1 ? whix : min(wx + (~(ux ^ smx) & m4), whix);
-                fwz = m4 >= n - 1 ? whiz : min(wz + (~(uz ^ smz) & m4), whiz);
-                fwy = smy == 0 ? whiy : min(wy + (int)(e & 0xfffu), whiy);
             } else {
-                const int r4 = (d - 1) << 2;
+                // Both kinds of box start at the ray's own cell and extend the way it travels (+ in the mirrored frame):
+                // the square of cell columns from its floor up to the top of the window, or the octant cube.
+                const bool columns = e != 0 && two > d;  // (measured: better than half and than twice that)
+                const int  r4 = columns ? 2 * two - 4 : (d - 1) << 2;  // voxels across the box, less those of the first cell
+                const int  upto = smy == 0 ? whiy : wy + (int)(e & 0xfffu);
                 fwx = min((wx | 3) + r4, whix);
-                fwy = min((wy | 3) + r4, whiy);
                 fwz = min((wz | 3) + r4, whiz);
+                fwy = min(columns ? upto : (wy | 3) + r4, whiy);
             }
             // plane parameters of the box's far faces (ln1 = ln + 1: the plane behind anchor fw)
             const float tx = (plane_float(fwx + ln1x) - rnx) * inx;
@@ -1645,8 +1645,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VRT_SEC_WAV
 
 static int trace_form(const TraceParams &p)
 {
-    // (FORM_POW2 addresses the cell records by 32-bit byte offsets: 32 * (n / 4)^3 <= 2^32)
-    return p.need_cap ? FORM_CAPPED : (p.n_pow2_mask >= 0 && p.n <= 2048 ? FORM_POW2 : FORM_ANY_N);
+    // (FORM_POW2 addresses the cells by 32-bit byte offsets: 128 * (n / 4)^3 <= 2^32)
+    return p.need_cap ? FORM_CAPPED : (p.n_pow2_mask >= 0 && p.n <= 1024 ? FORM_POW2 : FORM_ANY_N);
 }
 
 static dim3 trace_grid(const TraceParams &p)

@@ -179,10 +179,10 @@ hipError_t launch_terrain(void *block, int voxel_bytes, int n, int x0, int y0, i
 // ---------------------------------------------------------------------------
 // cell records: cell (cx,cy,cz) covers texels [4c, 4c+4)^3
 // ---------------------------------------------------------------------------
-// A cell's record and its column-top pyramid words lie side by side, 32 bytes per cell: `cells` points at the
-// record of cell 0 and cell i's is cells[2 * i]; the pyramid kernel writes `out`[2 * i] with out = cells + 1.  A ray
-// that lands in a cell reads both, and among rays that have little to do with each other that is one miss in the
-// L2 per cell instead of two.
+// A cell's record and its column-top words lie in one 128-byte line: `cells` points at the record of cell 0 and cell
+// i's is cells[CELL_U4 * i]; the column-top kernel writes out[CELL_U4 * i .. + 3] with out = cells + 1.  A ray that
+// lands in a cell reads the record and one of the words, and among rays that have little to do with each other that is
+// one miss in the L2 per cell instead of two.
 // Every builder below works on a box of cells of the torus: origin o (each coordinate in [0, nc)) and extent e
 // (1..nc per axis); the cell of a thread is (o + local) mod nc.  The whole torus is the box (0, nc); after a few
 // chunks have been regenerated only the cells whose records can have changed are visited (launch_update_cells).
@@ -202,9 +202,11 @@ VRT_DEV bool box_cell(const CellBox &b, int nc, int &cx, int &cy, int &cz)
 
 static dim3 box_grid(const CellBox &b) { return dim3((b.ex + 63) / 64, (b.ey + 3) / 4, b.ez); }
 
-// occupancy mask, bit = z*16 + y*4 + x; the distance words are filled by k_df_z_pack
+// occupancy mask, bit = z*16 + y*4 + x, into the builders' own plane of masks (8 bytes per cell, side by side: the
+// passes below read 32 masks ahead of every cell, which would be 32 lines of the 128-byte cells); k_df_z_pack writes a
+// cell's record, mask and distances, in one piece
 template <typename T>
-__global__ __launch_bounds__(256) void k_cell_masks(const T *block, int n, int nc, CellBox box, uint4 *cells)
+__global__ __launch_bounds__(256) void k_cell_masks(const T *block, int n, int nc, CellBox box, uint2 *masks)
 {
     int cx, cy, cz;
     if (!box_cell(box, nc, cx, cy, cz)) return;
@@ -225,8 +227,7 @@ __global__ __launch_bounds__(256) void k_cell_masks(const T *block, int n, int n
             m |= (uint64_t)bits << (z * 16 + y * 4);
         }
     }
-    uint2 *dst = reinterpret_cast<uint2 *>(cells + 2 * (((size_t)cz * nc + cy) * nc + cx));
-    *dst = make_uint2((unsigned)m, (unsigned)(m >> 32));
+    masks[((size_t)cz * nc + cy) * nc + cx] = make_uint2((unsigned)m, (unsigned)(m >> 32));
 }
 
 // The octant distances come from a separable transform.  One axis of it: out(p) = min over r >= 0 of
@@ -257,13 +258,13 @@ VRT_DEV int df_scan(LOAD value, int self, int pos, int nc, int dir)
 }
 
 // planes: tx[sx] at tx + sx * ncells
-__global__ __launch_bounds__(256) void k_df_x(const uint4 *cells, int nc, CellBox box, uint8_t *tx)
+__global__ __launch_bounds__(256) void k_df_x(const uint2 *masks, int nc, CellBox box, uint8_t *tx)
 {
     int cx, cy, cz;
     if (!box_cell(box, nc, cx, cy, cz)) return;
     const size_t ncells = (size_t)nc * nc * nc, line = ((size_t)cz * nc + cy) * nc;
     auto value = [&](int q) -> int {
-        const uint2 m = *reinterpret_cast<const uint2 *>(cells + 2 * (line + q));
+        const uint2 m = masks[line + q];
         return (m.x | m.y) != 0 ? 0 : DF_CAP;
     };
     const int self = value(cx);
@@ -287,8 +288,9 @@ __global__ __launch_bounds__(256) void k_df_y(const uint8_t *tx, int nc, CellBox
     }
 }
 
-// the eight octant distances of a cell, byte o = sx | sy << 1 | sz << 2, into the record's .z and .w words
-__global__ __launch_bounds__(256) void k_df_z_pack(const uint8_t *ty, int nc, CellBox box, uint4 *cells)
+// the eight octant distances of a cell, byte o = sx | sy << 1 | sz << 2, into the record's .z and .w words, behind the
+// cell's mask
+__global__ __launch_bounds__(256) void k_df_z_pack(const uint8_t *ty, const uint2 *masks, int nc, CellBox box, uint4 *cells)
 {
     int cx, cy, cz;
     if (!box_cell(box, nc, cx, cy, cz)) return;
@@ -302,8 +304,8 @@ __global__ __launch_bounds__(256) void k_df_z_pack(const uint8_t *ty, int nc, Ce
         lo |= (unsigned)df_scan(value, self, cz, nc, -1) << (8 * sxy);
         hi |= (unsigned)df_scan(value, self, cz, nc, 1) << (8 * sxy);
     }
-    uint2 *dst = reinterpret_cast<uint2 *>(cells + 2 * ((size_t)cz * plane + base)) + 1;
-    *dst = make_uint2(lo, hi);
+    const uint2 m = masks[(size_t)cz * plane + base];
+    cells[CELL_U4 * ((size_t)cz * plane + base)] = make_uint4(m.x, m.y, lo, hi);
 }
 
 // box [lo, lo + len) of an axis widened by `grow` cells on both sides, on a torus of nc cells
@@ -322,15 +324,17 @@ hipError_t launch_update_cells(const void *block, int voxel_bytes, int n, uint4 
     if (b.ex <= 0 || b.ey <= 0 || b.ez <= 0) return hipSuccess;
     const size_t ncells = (size_t)nc * nc * nc;
     const dim3 blockdim(256);
-    if (voxel_bytes == 1) k_cell_masks<uint8_t><<<box_grid(b), blockdim, 0, s>>>((const uint8_t *)block, n, nc, b, cells);
-    else k_cell_masks<uint16_t><<<box_grid(b), blockdim, 0, s>>>((const uint16_t *)block, n, nc, b, cells);
-    uint8_t *tx = planes, *ty = planes + 2 * ncells;
+    // planes: the masks (8 bytes per cell), the two x planes, the four y planes
+    uint2   *masks = reinterpret_cast<uint2 *>(planes);
+    uint8_t *tx = planes + 8 * ncells, *ty = planes + 10 * ncells;
+    if (voxel_bytes == 1) k_cell_masks<uint8_t><<<box_grid(b), blockdim, 0, s>>>((const uint8_t *)block, n, nc, b, masks);
+    else k_cell_masks<uint16_t><<<box_grid(b), blockdim, 0, s>>>((const uint16_t *)block, n, nc, b, masks);
     widen(b.ox, b.ex, DF_CAP - 1, nc);
-    k_df_x<<<box_grid(b), blockdim, 0, s>>>(cells, nc, b, tx);
+    k_df_x<<<box_grid(b), blockdim, 0, s>>>(masks, nc, b, tx);
     widen(b.oy, b.ey, DF_CAP - 1, nc);
     k_df_y<<<box_grid(b), blockdim, 0, s>>>(tx, nc, b, ty);
     widen(b.oz, b.ez, DF_CAP - 1, nc);
-    k_df_z_pack<<<box_grid(b), blockdim, 0, s>>>(ty, nc, b, cells);
+    k_df_z_pack<<<box_grid(b), blockdim, 0, s>>>(ty, masks, nc, b, cells);
     return hipGetLastError();
 }
 
@@ -341,34 +345,35 @@ hipError_t launch_build_cells(const void *block, int voxel_bytes, int n, uint4 *
 }
 
 // ---------------------------------------------------------------------------
-// column-top pyramid at voxel precision (TraceParams::pyr)
+// column tops at voxel precision (TraceParams::pyr)
 // ---------------------------------------------------------------------------
 // Levels are counted from the bottom of the loaded window: window layer wl of torus cell row tcy is
 // (tcy - offcy) mod nc, offcy = rem_euclid(lower_y, n) / 4, and window level v = 4*wl + (voxel row in the cell).
-// vtops[0][tcz][tcx] = window level just above the highest solid voxel of the 4x4 voxel columns of cell
-// column (tcx, tcz), 0 if they are empty; vtops[L] = max over aligned 2^L x 2^L blocks of cell columns.
+// tops[0][tcz][tcx] = window level just above the highest solid voxel of the 4x4 voxel columns of cell
+// column (tcx, tcz), 0 if they are empty; tops[L][tcz][tcx] = the maximum over the square of 2^L x 2^L cell columns
+// (tcx .. tcx + 2^L - 1) x (tcz .. tcz + 2^L - 1) of the torus -- a table per level, every cell column the corner of a
+// square of its own (not a pyramid of aligned blocks: a ray uses the square that starts at its own cell and extends the
+// way it travels, all of it, where an aligned block serves it only from wherever in the block the ray happens to be).
 // A cell is non-empty iff its octant distances are zero.
-__global__ __launch_bounds__(256) void k_tops_reduce(const uint16_t *fine, int nfine, uint16_t *coarse, int ncoarse)
+__global__ __launch_bounds__(256) void k_tops_extend(const uint16_t *fine, uint16_t *coarse, int nc, int half)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int z = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= ncoarse || z >= ncoarse) return;
-    unsigned v = 0;
-    for (int dz = 0; dz < 2; ++dz)
-        for (int dx = 0; dx < 2; ++dx) {
-            const int fx = 2 * x + dx, fz = 2 * z + dz;
-            if (fx < nfine && fz < nfine) v = max(v, (unsigned)fine[(size_t)fz * nfine + fx]);
-        }
-    coarse[(size_t)z * ncoarse + x] = (uint16_t)v;
+    if (x >= nc || z >= nc) return;
+    int x1 = x + half, z1 = z + half;
+    x1 -= x1 >= nc ? nc : 0;
+    z1 -= z1 >= nc ? nc : 0;
+    const unsigned a = fine[(size_t)z * nc + x], b = fine[(size_t)z * nc + x1];
+    const unsigned c = fine[(size_t)z1 * nc + x], d = fine[(size_t)z1 * nc + x1];
+    coarse[(size_t)z * nc + x] = (uint16_t)max(max(a, b), max(c, d));
 }
 
-struct PyramidLevels {
-    const uint16_t *tops[9];  // [0..8]
-    int             size[9];  // blocks per axis
-    int             levels;   // highest level present
+struct TopsLevels {
+    const uint16_t *tops[TOPS_LEVELS];  // nc x nc each
+    int             levels;             // highest level present: squares of 2^levels <= nc cell columns
 };
 
-__global__ __launch_bounds__(256) void k_column_vtops(const uint4 *cells, int nc, int offcy, uint16_t *tops0)
+__global__ __launch_bounds__(256) void k_column_vtops(const uint2 *masks, int nc, int offcy, uint16_t *tops0)
 {
     const int tcx = blockIdx.x * 64 + (threadIdx.x & 63);
     const int tcz = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -377,8 +382,8 @@ __global__ __launch_bounds__(256) void k_column_vtops(const uint4 *cells, int nc
     for (int wl = nc - 1; wl >= 0; --wl) {
         int tcy = wl + offcy;
         tcy -= tcy >= nc ? nc : 0;
-        const uint4 rec = cells[2 * (((size_t)tcz * nc + tcy) * nc + tcx)];
-        if ((rec.z & 0xffu) != 0) continue;  // empty cell
+        const uint2 rec = masks[((size_t)tcz * nc + tcy) * nc + tcx];
+        if ((rec.x | rec.y) == 0) continue;  // empty cell
         const uint64_t m = (uint64_t)rec.x | ((uint64_t)rec.y << 32);
         int y = 3;
         while (y > 0 && (m & (0x000F000F000F000Full << (4 * y))) == 0) --y;
@@ -388,68 +393,78 @@ __global__ __launch_bounds__(256) void k_column_vtops(const uint4 *cells, int nc
     tops0[(size_t)tcz * nc + tcx] = (uint16_t)v;
 }
 
-__global__ __launch_bounds__(256) void k_voxel_pyramid(int nc, int offcy, PyramidLevels pyr, uint4 *out)
+// The eight words of a cell: word = descending | negative x << 1 | negative z << 2.  One thread per cell and pair of
+// words (a quadrant of travel, negative x | negative z << 1), the four threads of a cell side by side: 64 bytes in a row.
+__global__ __launch_bounds__(256) void k_voxel_pyramid(int nc, int offcy, TopsLevels tl, uint4 *out)
 {
-    const int tcx = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int tcy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int tx = blockIdx.x * 256 + threadIdx.x;
+    const int tcx = tx >> 2, q = tx & 3;
+    const int tcy = blockIdx.y;
     const int tcz = blockIdx.z;
-    if (tcx >= nc || tcy >= nc) return;
+    if (tcx >= nc) return;
     int wl = tcy - offcy;
     wl += wl < 0 ? nc : 0;
-    // Any level whose block top lies at or below the voxel gives a valid box; two choices are kept.
-    //   up[j]    the widest block: for rays that rise, which leave a block through its sides only
-    //   down[j]  the largest min(block width, 4 * height above the block's top): a wide block with
-    //            little room underneath ends a descending ray after a few voxels (measured on the bench
-    //            frame: 58 us against 62 us with the widest block; factors 2..4 alike, 1 worse)
-    unsigned up[4], down[4];
-    for (int j = 0; j < 4; ++j) {
-        const int v = 4 * wl + j;
-        unsigned widest = 0, best = 0;
-        int score = -1;
-        for (int L = 0; L <= pyr.levels; ++L) {
-            const int t = (int)pyr.tops[L][(size_t)(tcz >> L) * pyr.size[L] + (tcx >> L)];
-            if (t > v) break;  // tops grow with L
+    // the square of level L that extends towards -x has its corner 2^L - 1 columns before the cell
+    const bool negx = (q & 1) != 0, negz = (q & 2) != 0;
+    // Any level whose square lies at or below the voxel gives a valid box; two choices are kept.
+    //   up[j]    the widest square: for rays that rise, which leave a box through its sides only
+    //   down[j]  the largest min(side, 4 * height above the square's top): a wide square with little room
+    //            underneath ends a descending ray after a few voxels (measured with aligned blocks on the bench
+    //            frame: 58 us against 62 us with the widest; factors 2..4 alike, 1 worse)
+    unsigned up[4] = {0, 0, 0, 0}, down[4] = {0, 0, 0, 0};
+    int      score[4] = {-1, -1, -1, -1};
+    for (int L = 0; L <= tl.levels; ++L) {
+        const int back = (1 << L) - 1;
+        int x = negx ? tcx - back : tcx, z = negz ? tcz - back : tcz;
+        x += x < 0 ? nc : 0;
+        z += z < 0 ? nc : 0;
+        const int t = (int)tl.tops[L][(size_t)z * nc + x];
+        if (t > 4 * wl + 3) break;  // tops grow with L
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int v = 4 * wl + j;
+            if (t > v) continue;
             const unsigned e = ((unsigned)(L + 1) << 12) | (unsigned)min(v - t, 4095);
             const int sc = min(4 << L, 4 * (v - t + 1));
-            widest = e;
-            if (sc >= score) { score = sc; best = e; }
+            up[j] = e;
+            if (sc >= score[j]) { score[j] = sc; down[j] = e; }
         }
-        up[j] = widest; down[j] = best;
     }
-    out[2 * (((size_t)tcz * nc + tcy) * nc + tcx)] =
+    out[CELL_U4 * (((size_t)tcz * nc + tcy) * nc + tcx) + q] =
         make_uint4(up[0] | (up[1] << 16), up[2] | (up[3] << 16), down[0] | (down[1] << 16), down[2] | (down[3] << 16));
 }
 
-hipError_t launch_build_voxel_pyramid(const uint4 *cells, int nc, int offcy, uint16_t *tops, uint4 *out, hipStream_t s)
+hipError_t launch_build_voxel_pyramid(const uint8_t *planes, int nc, int offcy, uint16_t *tops, uint4 *out, hipStream_t s)
 {
-    const dim3 blockdim(256);
-    PyramidLevels pyr{};
+    const dim3 blockdim(256), grid2((nc + 63) / 64, (nc + 3) / 4);
+    TopsLevels tl{};
     uint16_t *level = tops;
-    int       size = nc;
-    k_column_vtops<<<dim3((nc + 63) / 64, (nc + 3) / 4), blockdim, 0, s>>>(cells, nc, offcy, level);
-    pyr.tops[0] = level; pyr.size[0] = size; pyr.levels = 0;
-    for (int L = 1; L <= 8; ++L) {
-        if (nc % (1 << L) != 0) break;  // blocks are aligned in torus cell coordinates
-        uint16_t *coarse = level + (size_t)size * size;
-        k_tops_reduce<<<dim3(((nc >> L) + 63) / 64, ((nc >> L) + 3) / 4), blockdim, 0, s>>>(level, size, coarse, nc >> L);
-        level = coarse; size = nc >> L;
-        pyr.tops[L] = level; pyr.size[L] = size; pyr.levels = L;
+    k_column_vtops<<<grid2, blockdim, 0, s>>>(reinterpret_cast<const uint2 *>(planes), nc, offcy, level);
+    tl.tops[0] = level; tl.levels = 0;
+    for (int L = 1; L < TOPS_LEVELS; ++L) {
+        if ((1 << L) > nc) break;
+        uint16_t *coarse = level + (size_t)nc * nc;
+        k_tops_extend<<<grid2, blockdim, 0, s>>>(level, coarse, nc, 1 << (L - 1));
+        level = coarse;
+        tl.tops[L] = level; tl.levels = L;
     }
-    k_voxel_pyramid<<<dim3((nc + 63) / 64, (nc + 3) / 4, nc), blockdim, 0, s>>>(nc, offcy, pyr, out);
+    k_voxel_pyramid<<<dim3((4 * nc + 255) / 256, nc, nc), blockdim, 0, s>>>(nc, offcy, tl, out);
     return hipGetLastError();
 }
 
-// dst[i] = src[2 * i]: the records, or the pyramid words, out of the 32-byte cells
-__global__ __launch_bounds__(256) void k_copy_every_other(const uint4 *src, uint4 *dst, size_t count)
+// dst[i * part + j] = src[CELL_U4 * i + j]: the records, or the column-top words, out of the 128-byte cells
+__global__ __launch_bounds__(256) void k_copy_cell_part(const uint4 *src, uint4 *dst, size_t count, unsigned part)
 {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < count) dst[i] = src[2 * i];
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= count * part) return;
+    const size_t i = t / part, j = t % part;
+    dst[t] = src[CELL_U4 * i + j];
 }
 
-hipError_t launch_copy_every_other(const uint4 *src, uint4 *dst, size_t count, hipStream_t s)
+hipError_t launch_copy_cell_part(const uint4 *src, uint4 *dst, size_t count, unsigned part, hipStream_t s)
 {
-    if (count == 0) return hipSuccess;
-    k_copy_every_other<<<(unsigned)((count + 255) / 256), 256, 0, s>>>(src, dst, count);
+    if (count == 0 || part == 0) return hipSuccess;
+    k_copy_cell_part<<<(unsigned)((count * part + 255) / 256), 256, 0, s>>>(src, dst, count, part);
     return hipGetLastError();
 }
 

@@ -164,11 +164,11 @@ class GraphicsCore:
         return out
 
     def download_index(self, pyramid=False):
-        """The traversal index as the device holds it: cell records, and optionally the column-top pyramid words,
-        each (n/4)^3 x 4 uint32.  Brings the index up to date first."""
+        """The traversal index as the device holds it: cell records, (n/4)^3 x 4 uint32, and optionally the cells'
+        column-top words, (n/4)^3 x 16 uint32 (eight 64-bit words per cell).  Brings the index up to date first."""
         nc = self.grid_n // 4
         cells = np.empty((nc ** 3, 4), np.uint32)
-        pyr = np.empty((nc ** 3, 4), np.uint32) if pyramid else None
+        pyr = np.empty((nc ** 3, 16), np.uint32) if pyramid else None
         L.check(L.lib().vrt_download_index(self._ctx, cells.ctypes.data, pyr.ctypes.data if pyramid else None, L.MEM_HOST))
         return (cells, pyr) if pyramid else cells
 

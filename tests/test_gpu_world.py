@@ -120,3 +120,58 @@ def test_index_updated_chunk_by_chunk_equals_an_index_built_whole(render_distanc
                 if x.dtype == np.float32:
                     x, y = x.view(np.uint32), y.view(np.uint32)
                 assert np.array_equal(x, y), k
+
+
+@pytest.mark.parametrize("n,kind", [(64, "random"), (96, "terrain"), (160, "terrain")])
+def test_column_top_words_against_their_definition_in_numpy(n, kind):
+    """Every entry of the cells' column-top words, as downloaded, against the definition worked out here from the
+    voxels alone: entry (L + 1) << 12 | drop of voxel level v of a cell means that the square of 2^L x 2^L cell columns
+    with the cell's column at its corner, extending the way the word's rays travel, holds no solid voxel at or above
+    window level v - drop; rising words hold the widest such square, descending words the one with the largest
+    min(side in voxels, 4 * (drop + 1)), the wider of equals."""
+    rng = np.random.default_rng(11)
+    pose = scenes.pose_b(9.3)
+    wmin = scenes.window_min(pose.get_position(), n)
+    if kind == "terrain":
+        block = O.terrain_fill(n, wmin, np.uint8)
+    else:
+        block = (rng.random((n, n, n)) < 0.004).astype(np.uint8)
+        block[:, : n // 3, :] |= (rng.random((n, n // 3, n)) < 0.3).astype(np.uint8)
+    nc = n // 4
+    with GraphicsCore(grid_n=n, voxel_format=VOXEL_PACKED_U8, trace_mode=TRACE_SKIP) as g:
+        g.upload_world(block)
+        g.reset_distance_field()
+        g.trace(scenes.cam16(pose), 64, 48, outputs=("bgra8",))   # levels the words for this camera's window
+        _, words = g.download_index(pyramid=True)
+    words = words.reshape(nc, nc, nc, 4, 2, 2).astype(np.int64)          # [tcz, tcy, tcx, quadrant, up/down, half]
+    entries = np.stack([words[..., 0] & 0xffff, words[..., 0] >> 16, words[..., 1] & 0xffff, words[..., 1] >> 16], -1)  # [..., j]
+    # window level of every texel row: texel = rem_euclid(world, n), world = wmin + level
+    off = int(wmin[1]) % n
+    solid = np.roll(block != 0, -off, axis=1)                              # [tz, level, tx]
+    lvl = np.arange(1, n + 1)[None, :, None]
+    top = (solid * lvl).max(axis=1).reshape(nc, 4, nc, 4).max(axis=(1, 3))  # [tcz, tcx]: level just above the highest solid voxel
+    tables = [top]
+    while (2 << (len(tables) - 1)) <= nc and len(tables) < 9:
+        h, t = 1 << (len(tables) - 1), tables[-1]
+        t = np.maximum(t, np.roll(t, -h, axis=1))
+        tables.append(np.maximum(t, np.roll(t, -h, axis=0)))
+    offc = off // 4
+    wl = (np.arange(nc) - offc) % nc                                       # window layer of torus cell row tcy
+    for q in range(4):
+        negx, negz = q & 1, q >> 1
+        up = np.zeros((nc, nc, nc, 4), np.int64)
+        down = np.zeros((nc, nc, nc, 4), np.int64)
+        score = np.full((nc, nc, nc, 4), -1, np.int64)
+        v = (4 * wl[None, :, None, None] + np.arange(4)[None, None, None, :])
+        for L, t in enumerate(tables):
+            back = (1 << L) - 1
+            tq = np.roll(t, (back if negz else 0, back if negx else 0), axis=(0, 1))[:, None, :, None]   # [tcz, 1, tcx, 1]
+            ok = tq <= v
+            e = ((L + 1) << 12) | np.minimum(v - tq, 4095)
+            sc = np.minimum(4 << L, 4 * (v - tq + 1))
+            up = np.where(ok, e, up)
+            better = ok & (sc >= score)
+            down = np.where(better, e, down)
+            score = np.where(better, sc, score)
+        assert np.array_equal(entries[:, :, :, q, 0, :], up), (q, "rising")
+        assert np.array_equal(entries[:, :, :, q, 1, :], down), (q, "descending")

@@ -36,7 +36,7 @@ for d in sorted(glob.glob(os.path.join(out_dir, "pmc_*"))):
 
 W, H = 1920, 1080
 record = {"_note": "Counters per launch of k_trace_skip<u8, pow2> on the bench.py workload (1920x1080 over 1024^3), rocprofv3 --pmc passes of "
-                   "`bench.py --warmup 1 --steps 200 --probe 16 --no-cpu-baseline --no-literal` (tools/profile_r03.sh, one run per pass), "
+                   "`bench.py --warmup 1 --steps 200 --probe 16 --settle-ms 0 --no-cpu-baseline --no-literal` (tools/profile_r03.sh, one run per pass), "
                    "means over the 17 launches that run one at a time (measured dispatch order) and over the 201 that overlap on two "
                    "streams (rows in plain order, no dispatch-order bookkeeping).  FETCH_SIZE and WRITE_SIZE are KiB; FETCH_SIZE is doubled "
                    "(gfx950 tallies 128-byte fills as 64 bytes; TCC_EA0_RDREQ_32B = 0), WRITE_SIZE taken as reported.  kernel_sources: git "

@@ -3,7 +3,7 @@
 # (rocprofv3 does not split counters over passes), then tools/make_traffic.py turns them into the record bench.py
 # prices (traffic.json) and a readable summary.  On the GPU box, from the repo root:
 #   bash tools/profile_r03.sh [tag]        -> gpurun_out/<tag>/{traffic.json,summary.txt}
-# The command of every pass: bench.py --warmup 1 --steps 200 --probe 16 --no-cpu-baseline --no-literal, i.e. one set-up
+# The command of every pass: bench.py --warmup 1 --steps 200 --probe 16 --settle-ms 0 --no-cpu-baseline --no-literal, i.e. one set-up
 # launch, 201 overlapped launches (two streams, rows in plain order) and 16 launches one at a time (measured dispatch order).
 TAG=${1:-r03prof}
 OUT=gpurun_out/$TAG
@@ -12,7 +12,7 @@ export TMPDIR=/tmp
 run_pass() {
   name=$1; shift
   timeout -s KILL 150 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/pmc_$name" -- \
-      python3 bench.py --warmup 1 --steps 200 --probe 16 --no-cpu-baseline --no-literal > "$OUT/pmc_$name.log" 2>&1
+      python3 bench.py --warmup 1 --steps 200 --probe 16 --settle-ms 0 --no-cpu-baseline --no-literal > "$OUT/pmc_$name.log" 2>&1
   rc=$?
   echo "pass $name rc=$rc"
   [ $rc -eq 0 ] || tail -n 5 "$OUT/pmc_$name.log"

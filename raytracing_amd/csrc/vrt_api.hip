@@ -291,7 +291,7 @@ int ensure_skip_structure(vrt_ctx *c, int offcy)
         c->pyr_offcy = -1;
     }
     if (offcy >= 0 && c->pyr_offcy != offcy) {
-        HIP_TRY(vrt::launch_build_voxel_pyramid(c->d_build, (int)c->n / 4, offcy, c->d_tops, c->d_pyr, c->stream));
+        HIP_TRY(vrt::launch_build_voxel_pyramid(c->d_build, (int)c->n / 4, offcy, c->d_tops, c->d_cells, c->stream));
         c->pyr_offcy = offcy;
     }
     if (work) return fork_lanes(c);

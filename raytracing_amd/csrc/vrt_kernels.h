@@ -16,6 +16,8 @@ namespace vrt {
 constexpr unsigned CELL_U4 = 8;     // uint4 units per cell
 constexpr unsigned CELL_SHIFT = 7;  // log2 of its bytes
 constexpr unsigned PYR_U4 = 4;      // uint4 units of column-top words per cell, from cells[CELL_U4 * i + 1]
+constexpr unsigned BOX_NONE = 0xffffu;   // entry of a box word: no empty box known, the ray steps voxel by voxel
+constexpr unsigned BOX_RISE_ALL = 0xffu;  // ... its rise field: up to the top of the window
 constexpr unsigned PLANE_BYTES_PER_CELL = 14;  // launch_build_cells' planes: masks 8, x planes 2, y planes 4
 constexpr int      TOPS_LEVELS = 9; // tables of column tops: squares of 1, 2, .. 256 cell columns
 
@@ -82,14 +84,15 @@ struct TraceParams {
     //          that octant; 0 = the cell is non-empty, cap 32
     const uint4 *cells;
     int32_t  nc;                // n / 4
-    // column-top words at voxel precision, eight 64-bit words per cell (any cell, empty or not), word
-    // w = descending | negative x << 1 | negative z << 2 for the ray's direction of travel, at byte 16 + 8 * w of the
-    // cell: for each of the cell's four voxel levels j a 16-bit entry (L + 1) << 12 | drop -- the square of 2^L x 2^L cell
-    // columns that has the cell's own column at its corner and extends the way the ray travels (towards -x for a
-    // "negative x" word, ...) holds no voxel at or above window level (4*layer + j) - drop (drop capped at 4095);
-    // 0 = not even the cell's own column qualifies.  Window levels are counted from the bottom of the loaded window, so
-    // the words are rebuilt when the window's vertical offset changes.  Words of rays that rise hold the widest such
-    // square, words of rays that descend the square the builder prefers for them.
+    // box words, eight 64-bit words per cell (any cell, empty or not), word w = descending | negative x << 1 |
+    // negative z << 2 for the ray's direction of travel, at byte 16 + 8 * w of the cell: for each of the cell's four voxel
+    // levels j a 16-bit entry, the empty box a ray crosses from a voxel of that level -- BOX_NONE, or (side - 1) << 8 |
+    // rise: `side` cells along x and z from the ray's own cell on the way it travels, and `rise` voxels more along y from
+    // the voxel on (BOX_RISE_ALL: up to the top of the window).  The builder (vrt_world.hip, k_voxel_pyramid) puts the
+    // better of two boxes there: the square of cell columns that hold no voxel at or above some window level (a table of
+    // column tops per square size; valid above the solid voxels of a non-empty cell too), or the octant cube of the
+    // record.  Window levels are counted from the bottom of the loaded window, so the words are rebuilt when the window's
+    // vertical offset changes, and whenever records change.
     const uint4 *pyr;           // cells + 1
     // per-frame tables (device memory, filled by launch_frame_tables with the kernels' own arithmetic;
     // null = evaluate in place): the two divisions of raytrace.glsl:121 per column / per row, and the
@@ -133,8 +136,9 @@ hipError_t launch_build_cells(const void *block, int voxel_bytes, int n, uint4 *
 // for every cell around it whose distances depend on them.
 hipError_t launch_update_cells(const void *block, int voxel_bytes, int n, uint4 *cells, uint8_t *planes, const int origin[3],
                                const int extent[3], hipStream_t s);
-// planes: as launch_build_cells left them (the masks are read); tops: scratch of at least TOPS_LEVELS * nc * nc uint16_t; offcy = rem_euclid(lower_y, n) / 4; pyr = cells + 1 (cell i's words from pyr[CELL_U4 * i])
-hipError_t launch_build_voxel_pyramid(const uint8_t *planes, int nc, int offcy, uint16_t *tops, uint4 *pyr, hipStream_t s);
+// planes and cells: as launch_build_cells left them (the masks and the records' distances are read); tops: scratch of at least
+// TOPS_LEVELS * nc * nc uint16_t; offcy = rem_euclid(lower_y, n) / 4; writes the box words of every cell (cells[CELL_U4 * i + 1 .. + 4])
+hipError_t launch_build_voxel_pyramid(const uint8_t *planes, int nc, int offcy, uint16_t *tops, uint4 *cells, hipStream_t s);
 hipError_t launch_frame_tables(float *ncx, float *ncy, float *sin2, uint32_t w, uint32_t h, float ncy_off,
                                const int32_t sin_base[3], uint32_t sin_len, hipStream_t s);
 // dst[i * part + j] = src[CELL_U4 * i + j], j < part: the records (src = cells, part = 1) or the column-top words

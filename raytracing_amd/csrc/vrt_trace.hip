@@ -389,17 +389,18 @@ VRT_DEV void traverse_skip(const TraceParams &P, float rox, float roy, float roz
 // whose ray is live, finish() turns the end state into the reference's outputs.  traverse_cells
 // below runs one ray per lane to the end; the stream kernel keeps lanes busy by starting a new ray
 // in a lane whose ray has ended.
-template <typename T, bool POW2>
+// POW2: 0 = any grid (texel wrap by subtraction, 64-bit cell addresses); 1 = power-of-two grid up to 1024 (wrap by bit
+// fields, 32-bit byte offsets); 2 = power-of-two grid above that (bit fields, 64-bit byte offsets)
+template <typename T, int POW2>
 struct CellRay {
     // per ray constants (mirrored frame)
     float rnx, rny, rnz, dnx, dny, dnz, inx, iny, inz, thr0x, thr0y, thr0z;
     int   lnx, lny, lnz, ln1x, ln1y, ln1z, smx, smy, smz;  // (ln1 = ln + 1 + PLANE_BIAS, see plane_float)
-    unsigned dsel;  // byte selector (v_perm_b32) of this ray's octant distance in the record's two distance words
-    unsigned psel;  // byte offset, in a cell, of the column-top word for this ray's direction of travel
+    unsigned psel;  // byte offset, in a cell, of the box word for this ray's direction of travel
     // state
-    int      wx, wy, wz, w0, k, d, bit;
-    unsigned pyr_lo, pyr_hi;  // the cell's word of the voxel-precision column-top pyramid
-    unsigned e;               // that word's entry for the current voxel's level (0: none), kept beside `bit`
+    int      wx, wy, wz, w0, k, bit;
+    unsigned pyr_lo, pyr_hi;  // the cell's box word for this ray's direction of travel
+    unsigned e;               // that word's entry for the current voxel's level (BOX_NONE: no box, unit steps), kept beside `bit`
     unsigned work, iters;
     uint64_t cur_mask;
     bool     live, hit;
@@ -415,15 +416,17 @@ struct CellRay {
     static constexpr int PLANE_BIAS = 0x4B400000;
     static VRT_DEV float plane_float(int biased) { return __int_as_float(biased) - 12582912.0f; }
 
-    // entry of the pyramid word for voxel level j (0..3): bytes 2j, 2j + 1 of the 64-bit word, cut out by one
-    // byte permute (selector bytes: 0..3 = pyr_lo, 4..7 = pyr_hi, 0x0c = zero).  The selector's constant half is OR-ed
-    // in as a literal of the instruction itself: held in a vector register across the secondary-ray kernel's loop (what
-    // the compiler does with it when it sees a multiply-add) the binned kernel's results came out wrong on the device.
+    // entry of the box word for voxel level j (0..3): bytes 2j (rise) and 2j + 1 (side - 1) of the 64-bit word, cut out by
+    // one byte permute into bits 0..7 and 16..23 (selector bytes: 0..3 = pyr_lo, 4..7 = pyr_hi, 0x0c = zero), so that
+    // 4 * (side - 1) is one right shift.  The selector's constant half is OR-ed in as a literal of the instruction itself:
+    // held in a vector register across the secondary-ray kernel's loop (what the compiler does with it when it sees a
+    // multiply-add) the binned kernel's results came out wrong on the device.
+    static constexpr unsigned NO_BOX = ((BOX_NONE >> 8) << 16) | (BOX_NONE & 0xffu);  // BOX_NONE spread the same way
     VRT_DEV unsigned entry_of(unsigned j) const
     {
         unsigned sel;
-        const unsigned t = 0x0202u * j;
-        asm("v_or_b32 %0, 0x0c0c0100, %1" : "=v"(sel) : "v"(t));
+        const unsigned t = 0x00020002u * j;
+        asm("v_or_b32 %0, 0x0c010c00, %1" : "=v"(sel) : "v"(t));
         return __builtin_amdgcn_perm(pyr_hi, pyr_lo, sel);
     }
     VRT_DEV unsigned entry() const { return entry_of(((unsigned)bit >> 2) & 3u); }
@@ -435,29 +438,34 @@ struct CellRay {
     {
         const int n = P.n, nc = P.nc;
         int qx = (wx ^ smx) + P.off[0], qy = (wy ^ smy) + P.off[1], qz = (wz ^ smz) + P.off[2];
-        uint4 r;
-        uint2 pw;
+        uint2 r, pw;  // the cell's occupancy mask (the record's first half), its box word for this ray
         if (POW2) {
-            // (n <= 1024 in this form.)  The cell's coordinates are bit fields of the texel coordinates, which need no
+            // The cell's coordinates are bit fields of the texel coordinates, which need no
             // wrap of their own then (the field extraction drops the bits above the grid, off is a multiple of 4), and
-            // the byte offset of the cell's 128 bytes stays below 2^32: one 32-bit offset on the scalar base address,
-            // the column-top word of the ray's direction of travel at psel (16 .. 72) behind it.
+            // for n <= 1024 (POW2 == 1) the byte offset of the cell's 128 bytes stays below 2^32: one 32-bit offset on the
+            // scalar base address, the column-top word of the ray's direction of travel at psel (16 .. 72) behind it.
             const unsigned L = (unsigned)P.nc_log2;
             const unsigned cx = __builtin_amdgcn_ubfe((unsigned)qx, 2u, L), cy = __builtin_amdgcn_ubfe((unsigned)qy, 2u, L),
                            cz = __builtin_amdgcn_ubfe((unsigned)qz, 2u, L);
-            const unsigned at = ((((cz << L) | cy) << L) | cx) << CELL_SHIFT;
+            const unsigned cell = (((cz << L) | cy) << L) | cx;
             const char *base = reinterpret_cast<const char *>(P.cells);
-            r  = *reinterpret_cast<const uint4 *>(base + at);
-            pw = *reinterpret_cast<const uint2 *>(base + (at | psel));
+            if (POW2 == 1) {
+                const unsigned at = cell << CELL_SHIFT;
+                r  = *reinterpret_cast<const uint2 *>(base + at);
+                pw = *reinterpret_cast<const uint2 *>(base + (at | psel));
+            } else {
+                const size_t at = (size_t)cell << CELL_SHIFT;
+                r  = *reinterpret_cast<const uint2 *>(base + at);
+                pw = *reinterpret_cast<const uint2 *>(base + at + psel);
+            }
         } else {
             qx -= qx >= n ? n : 0; qy -= qy >= n ? n : 0; qz -= qz >= n ? n : 0;
             const size_t cell = (size_t)(unsigned)(((qz >> 2) * nc + (qy >> 2)) * nc + (qx >> 2));
             const char *rec = reinterpret_cast<const char *>(P.cells) + (cell << CELL_SHIFT);  // the record, then the column-top words
-            r  = *reinterpret_cast<const uint4 *>(rec);
+            r  = *reinterpret_cast<const uint2 *>(rec);
             pw = *reinterpret_cast<const uint2 *>(rec + psel);
         }
         cur_mask = (uint64_t)r.x | ((uint64_t)r.y << 32);
-        d        = (int)__builtin_amdgcn_perm(r.w, r.z, dsel);
         // z * 16 + y * 4 + x of the voxel in its cell (off is a multiple of 4) in bits 0..5; what lies above them is
         // never looked at (mask_bit, entry)
         unsigned lvl = (unsigned)qy & 3u;
@@ -498,8 +506,6 @@ struct CellRay {
         asm volatile("" : "+v"(dnx), "+v"(dny), "+v"(dnz), "+v"(inx), "+v"(iny), "+v"(inz));
         lnx = px ? lox : -lox; lny = py ? loy : -loy; lnz = pz ? loz : -loz;
         ln1x = lnx + 1 + PLANE_BIAS; ln1y = lny + 1 + PLANE_BIAS; ln1z = lnz + 1 + PLANE_BIAS;
-        const int oct = (px ? 1 : 0) | (py ? 2 : 0) | (pz ? 4 : 0);
-        dsel = 0x0c0c0c00u | (unsigned)oct;  // byte `oct` of {r.z, r.w}, zero extended
         // word = descending | negative x << 1 | negative z << 2, eight bytes each, behind the 16-byte record
         psel = 16u + ((unsigned)smy & 8u) + ((unsigned)smx & 16u) + ((unsigned)smz & 32u);
         // margin of the exit-point test, as 0.5 - VRT_MARGIN * (|pos| + |origin| + 1) = thr0 - VRT_MARGIN * |pos|
@@ -513,7 +519,7 @@ struct CellRay {
         // loop test lower < a + s01 < upper  <=>  wlo <= w <= wlo + n - 3, wlo = 0 (s > 0) or 1 - n (s < 0)
         live = (unsigned)(wx - (smx & (1 - n))) <= span && (unsigned)(wy - (smy & (1 - n))) <= span &&
                (unsigned)(wz - (smz & (1 - n))) <= span;
-        d = 0; pyr_lo = pyr_hi = 0; e = 0; cur_mask = 0; bit = 0;
+        pyr_lo = pyr_hi = 0; e = NO_BOX; cur_mask = 0; bit = 0;
         if (live) locate(P);  // the anchor's cell (the start voxel itself is never tested)
     }
 
@@ -524,14 +530,14 @@ struct CellRay {
         return __float_as_uint(rnx) ^ __float_as_uint(rny) ^ __float_as_uint(rnz) ^ __float_as_uint(dnx) ^ __float_as_uint(dny) ^
                __float_as_uint(dnz) ^ __float_as_uint(inx) ^ __float_as_uint(iny) ^ __float_as_uint(inz) ^ __float_as_uint(thr0x) ^
                __float_as_uint(thr0y) ^ __float_as_uint(thr0z) ^ (unsigned)lnx ^ (unsigned)lny ^ (unsigned)lnz ^ (unsigned)smx ^
-               ((unsigned)smy << 1) ^ ((unsigned)smz << 2) ^ dsel ^ (unsigned)wx ^ ((unsigned)wy << 8) ^ ((unsigned)wz << 16) ^
-               (unsigned)w0 ^ (unsigned)d ^ (unsigned)bit ^ pyr_lo ^ pyr_hi ^ e ^ (unsigned)cur_mask ^ (unsigned)(cur_mask >> 32) ^
+               ((unsigned)smy << 1) ^ ((unsigned)smz << 2) ^ psel ^ (unsigned)wx ^ ((unsigned)wy << 8) ^ ((unsigned)wz << 16) ^
+               (unsigned)w0 ^ (unsigned)bit ^ pyr_lo ^ pyr_hi ^ e ^ (unsigned)cur_mask ^ (unsigned)(cur_mask >> 32) ^
                (live ? 1u : 0u);
     }
 #endif
 
     // a ray that ended elsewhere: the loop has nothing to do for this lane
-    VRT_DEV void idle() { live = false; hit = false; work = 0; iters = 0; wx = wy = wz = w0 = 0; d = 0; e = 0; }
+    VRT_DEV void idle() { live = false; hit = false; work = 0; iters = 0; wx = wy = wz = w0 = 0; e = NO_BOX; }
 
     // iterations of the reference's loop so far (every step moves one axis by +1 in the mirrored frame)
     VRT_DEV unsigned steps_done() const { return (unsigned)(wx + wy + wz - w0); }
@@ -553,9 +559,9 @@ struct CellRay {
         iters += 1u;
 #endif
 #ifdef VRT_DIAG_SEC_UTIL
-        dA += (d != 0 || e != 0) ? 1u : 0u;
+        dA += e != NO_BOX ? 1u : 0u;
 #endif
-        const bool boxed = d != 0 || e != 0;
+        const bool boxed = e != NO_BOX;
         bool fold = false;  // wave uniform
         if (FOLD > 0) {
             const unsigned walkers = (unsigned)__popcll(__ballot(boxed ? 0 : 1));
@@ -565,19 +571,17 @@ struct CellRay {
             // ---- phase A: cross an empty box that holds the current voxel: the column-top block of the
             // voxel's level (also inside a non-empty cell, above its solid voxels) or the octant cube
             int fwx, fwy, fwz;  // last anchor of the box on each axis
-            // the entry's square is 2^L x 2^L cell columns, L + 1 = e >> 12: twice its side in cells against the cube's
-            const int two = 1 << (e >> 12);
             if (FOLD > 0 && !boxed) {
                 fwx = wx; fwy = wy; fwz = wz;  // the voxel itself
             } else {
-                // Both kinds of box start at the ray's own cell and extend the way it travels (+ in the mirrored frame):
-                // the square of cell columns from its floor up to the top of the window, or the octant cube.
-                const bool columns = e != 0 && two > d;  // (measured: better than half and than twice that)
-                const int  r4 = columns ? 2 * two - 4 : (d - 1) << 2;  // voxels across the box, less those of the first cell
-                const int  upto = smy == 0 ? whiy : wy + (int)(e & 0xfffu);
+                // The box starts at the ray's own cell and extends the way the ray travels (+ in the mirrored frame): `side`
+                // cells along x and z, and from the voxel on `rise` voxels more along y, or to the top of the window (the
+                // builder has chosen between the square of cell columns and the octant cube, k_voxel_pyramid).
+                const int      r4 = (int)(e >> 14);  // 4 * (side - 1): the voxels across the box, less those of the first cell
+                const unsigned rise = e & 0xffu;
                 fwx = min((wx | 3) + r4, whix);
                 fwz = min((wz | 3) + r4, whiz);
-                fwy = min(columns ? upto : (wy | 3) + r4, whiy);
+                fwy = rise == BOX_RISE_ALL ? whiy : min(wy + (int)rise, whiy);
             }
             // plane parameters of the box's far faces (ln1 = ln + 1: the plane behind anchor fw)
             const float tx = (plane_float(fwx + ln1x) - rnx) * inx;
@@ -633,13 +637,13 @@ struct CellRay {
             // ends after that test (raytrace.glsl:52 comes before the next :43).  Only the exit axis can have
             // left the area (the other two stay inside the box), so "some axis beyond its bound" is that test.
             locate(P);  // a box ends at a cell boundary on its exit axis
-            if (d == 0 && mask_bit()) { hit = true; live = false; }
+            if (mask_bit()) { hit = true; live = false; }  // (an empty cell's mask is zero)
             else if (((int)(wx > whix) | (int)(wy > whiy) | (int)(wz > whiz)) != 0) live = false;
         }
 #ifdef VRT_DIAG_SEC_UTIL
-        dB1 += (!fold && live && d == 0 && e == 0) ? 1u : 0u;
+        dB1 += (!fold && live && e == NO_BOX) ? 1u : 0u;
 #endif
-        if (!fold && live && d == 0 && e == 0) {
+        if (!fold && live && e == NO_BOX) {
             // ---- phase B: a few unit steps through the non-empty cell(s)
             // change of the mask bit index (z*16 + y*4 + x of the unmirrored voxel) per unit step
             const int dbx = 1 | smx, dby = 4 ^ (smy & ~7), dbz = 16 ^ (smz & ~31);  // +-1, +-4, +-16
@@ -661,9 +665,9 @@ struct CellRay {
                 const int nxy = ky ? ny : nx, wk = cz ? nz : nxy;  // (locals: selects, not branches)
                 if ((wk & 3) == 0) locate(P);
                 else { const int dxy = ky ? dby : dbx; bit += cz ? dbz : dxy; e = entry(); }
-                if (d == 0 && mask_bit()) { hit = true; live = false; break; }
+                if (mask_bit()) { hit = true; live = false; break; }
                 if (((int)(nx > whix) | (int)(ny > whiy) | (int)(nz > whiz)) != 0) { live = false; break; }
-                if (d != 0 || e != 0) break;  // an empty box again: back to phase A
+                if (e != NO_BOX) break;  // an empty box again: back to phase A
             }
         }
     }
@@ -716,7 +720,7 @@ constexpr int PRIMARY_FOLD = VRT_PRIMARY_FOLD;  // CellRay::trip<FOLD> of rays t
 
 // A ray for which ray_is_regular holds, from the camera (CAMERA: origin = the launch's camera position, whose share
 // of the set-up the host has done) or from anywhere.
-template <typename T, bool POW2, bool CAMERA = false>
+template <typename T, int POW2, bool CAMERA = false>
 VRT_DEV void traverse_cells_regular(const TraceParams &P, float rox, float roy, float roz, float rdx, float rdy,
                                     float rdz, int lox, int loy, int loz, RayHit &H)
 {
@@ -736,7 +740,7 @@ VRT_DEV void traverse_cells_regular(const TraceParams &P, float rox, float roy, 
 
 // any ray: one that is not regular starts in the literal loop (NaN / inf semantics of the reference), which
 // hands it back when the rest of it is an ordinary ray in the other axes
-template <typename T, bool POW2>
+template <typename T, int POW2>
 VRT_DEV void traverse_cells(const TraceParams &P, float rox, float roy, float roz, float rdx, float rdy,
                             float rdz, int lox, int loy, int loz, int upx, int upy, int upz, RayHit &H)
 {
@@ -756,14 +760,16 @@ VRT_DEV void traverse_cells(const TraceParams &P, float rox, float roy, float ro
 // state of the other forms out of the scalar registers):
 //   FORM_CAPPED  one step per trip with the step cap tested (max_steps < 3n)
 //   FORM_POW2    two-phase loop, texel wrap by mask;   FORM_ANY_N  two-phase loop, wrap by subtraction
-enum { FORM_CAPPED = 0, FORM_POW2 = 1, FORM_ANY_N = 2 };
+//   FORM_POW2_WIDE  as FORM_POW2 for grids whose cells take more than 2^32 bytes (2048^3, 4096^3)
+enum { FORM_CAPPED = 0, FORM_POW2 = 1, FORM_ANY_N = 2, FORM_POW2_WIDE = 3 };
+constexpr int pow2_of(int form) { return form == FORM_POW2 ? 1 : (form == FORM_POW2_WIDE ? 2 : 0); }
 
 template <typename T, int FORM>
 VRT_DEV void traverse_auto(const TraceParams &P, float rox, float roy, float roz, float rdx, float rdy,
                            float rdz, int lox, int loy, int loz, int upx, int upy, int upz, RayHit &H)
 {
     if (FORM == FORM_CAPPED) traverse_skip<T>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
-    else traverse_cells<T, FORM == FORM_POW2>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
+    else traverse_cells<T, pow2_of(FORM)>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
 }
 
 // ---------------------------------------------------------------------------
@@ -1110,7 +1116,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         RayHit H;
         if (regular) {
             if (FORM == FORM_CAPPED) traverse_skip<T>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
-            else traverse_cells_regular<T, FORM == FORM_POW2, true>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, H);
+            else traverse_cells_regular<T, pow2_of(FORM), true>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, H);
             work = H.work;
         }
 #if defined(VRT_DIAG_STAGE) && VRT_DIAG_STAGE >= 2
@@ -1174,7 +1180,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VRT_STREAM_
     const unsigned block_rows = 4u << P.tile_log2h, total_rows = (P.rows.rows + block_rows - 1) / block_rows;
     const float rox = P.m[12], roy = P.m[13], roz = P.m[14];
     const int lox = P.lo[0], loy = P.lo[1], loz = P.lo[2];
-    CellRay<T, FORM == FORM_POW2> ray;
+    CellRay<T, pow2_of(FORM)> ray;
     ray.idle();
     unsigned j = 0;        // tiles this lane has started
     bool holding = false;  // the lane holds a ray of tile j - 1, live or ended and not yet finished
@@ -1304,7 +1310,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         if (FORM == FORM_CAPPED) {
             traverse_skip<T>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
         } else if (regular) {
-            traverse_cells_regular<T, FORM == FORM_POW2, true>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, H);
+            traverse_cells_regular<T, pow2_of(FORM), true>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, H);
         } else {
             float hp[3];
             const unsigned r = degenerate_primary<T, FORM>(params, gx, gy, hp);
@@ -1342,7 +1348,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 if (FORM == FORM_CAPPED) {
                     traverse_skip<T>(P, sox, soy, soz, sdx, sdy, sdz, lox, loy, loz, upx, upy, upz, S);
                 } else if (ray_is_regular(sdx, sdy, sdz)) {
-                    traverse_cells_regular<T, FORM == FORM_POW2>(P, sox, soy, soz, sdx, sdy, sdz, lox, loy, loz, S);
+                    traverse_cells_regular<T, pow2_of(FORM)>(P, sox, soy, soz, sdx, sdy, sdz, lox, loy, loz, S);
                 } else {
                     const unsigned r = degenerate_ray<T, FORM>(params, sox, soy, soz, sdx, sdy, sdz);
                     S.hit = (int)(r >> 31); S.steps = r & 0x7fffffffu; S.work = 0;
@@ -1448,7 +1454,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VRT_SEC_WAV
         if (FORM == FORM_CAPPED) {
             traverse_skip<T>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
         } else if (regular) {
-            traverse_cells_regular<T, FORM == FORM_POW2, true>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, H);
+            traverse_cells_regular<T, pow2_of(FORM), true>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, H);
         } else {
             float hp[3];
             const unsigned r = degenerate_primary<T, FORM>(params, gx, gy, hp);
@@ -1534,7 +1540,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VRT_SEC_WAV
         const unsigned lane = tid & 63u;
         float lightx, lighty, lightz;
         secondary_dir(0u, 0u, 0, lightx, lighty, lightz);  // the shadow rays' one direction
-        CellRay<T, FORM == FORM_POW2> ray;
+        CellRay<T, pow2_of(FORM)> ray;
         ray.idle();
         constexpr unsigned NO_RAY = 0xffffffffu;
         unsigned mine = NO_RAY;  // pixel | ray index << 8 of the ray this lane holds, live or ended and not yet delivered
@@ -1597,7 +1603,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VRT_SEC_WAV
 #ifdef VRT_DIAG_SEC_UTIL
             dLive += ray.live ? 1u : 0u;
             if (drained) { dTailTrips += 1u; dTailLive += ray.live ? 1u : 0u; }
-            ray.dAx += __any((ray.live && (ray.d != 0 || ray.entry() != 0)) ? 1 : 0) ? 1u : 0u;
+            ray.dAx += __any((ray.live && ray.entry() != ray.NO_BOX) ? 1 : 0) ? 1u : 0u;
 #endif
             if (ray.live) ray.template trip<SEC_FOLD>(P);
         }
@@ -1646,7 +1652,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VRT_SEC_WAV
 static int trace_form(const TraceParams &p)
 {
     // (FORM_POW2 addresses the cells by 32-bit byte offsets: 128 * (n / 4)^3 <= 2^32)
-    return p.need_cap ? FORM_CAPPED : (p.n_pow2_mask >= 0 && p.n <= 1024 ? FORM_POW2 : FORM_ANY_N);
+    if (p.need_cap) return FORM_CAPPED;
+    if (p.n_pow2_mask < 0) return FORM_ANY_N;
+    return p.n <= 1024 ? FORM_POW2 : FORM_POW2_WIDE;
 }
 
 static dim3 trace_grid(const TraceParams &p)
@@ -1678,6 +1686,7 @@ hipError_t launch_trace_secondary(const TraceParams &p, int voxel_bytes, bool bi
 #define VRT_LAUNCH_SECONDARY(K, T)                                                           \
     (form == FORM_CAPPED ? K<T, FORM_CAPPED><<<grid, block, 0, s>>>(p, shadow, ao, sec_steps) \
      : form == FORM_POW2 ? K<T, FORM_POW2><<<grid, block, 0, s>>>(p, shadow, ao, sec_steps)   \
+     : form == FORM_POW2_WIDE ? K<T, FORM_POW2_WIDE><<<grid, block, 0, s>>>(p, shadow, ao, sec_steps) \
                          : K<T, FORM_ANY_N><<<grid, block, 0, s>>>(p, shadow, ao, sec_steps))
     if (binned) {
         if (voxel_bytes == 1) VRT_LAUNCH_SECONDARY(k_trace_secondary_binned, uint8_t);
@@ -1712,9 +1721,11 @@ hipError_t launch_trace_skip(const TraceParams &p, int voxel_bytes, hipStream_t 
         const dim3 sgrid(grid.x, (grid.y + VRT_PRIMARY_STREAM - 1) / VRT_PRIMARY_STREAM, 1);
         if (voxel_bytes == 1) {
             if (form == FORM_POW2) k_trace_skip_stream<uint8_t, FORM_POW2><<<sgrid, block, 0, s>>>(p);
+            else if (form == FORM_POW2_WIDE) k_trace_skip_stream<uint8_t, FORM_POW2_WIDE><<<sgrid, block, 0, s>>>(p);
             else k_trace_skip_stream<uint8_t, FORM_ANY_N><<<sgrid, block, 0, s>>>(p);
         } else {
             if (form == FORM_POW2) k_trace_skip_stream<uint16_t, FORM_POW2><<<sgrid, block, 0, s>>>(p);
+            else if (form == FORM_POW2_WIDE) k_trace_skip_stream<uint16_t, FORM_POW2_WIDE><<<sgrid, block, 0, s>>>(p);
             else k_trace_skip_stream<uint16_t, FORM_ANY_N><<<sgrid, block, 0, s>>>(p);
         }
         return hipGetLastError();
@@ -1723,6 +1734,7 @@ hipError_t launch_trace_skip(const TraceParams &p, int voxel_bytes, hipStream_t 
 #define VRT_LAUNCH_SKIP(T)                                                              \
     (form == FORM_CAPPED ? k_trace_skip<T, FORM_CAPPED><<<grid, block, 0, s>>>(p)         \
      : form == FORM_POW2 ? k_trace_skip<T, FORM_POW2><<<grid, block, 0, s>>>(p)           \
+     : form == FORM_POW2_WIDE ? k_trace_skip<T, FORM_POW2_WIDE><<<grid, block, 0, s>>>(p) \
                          : k_trace_skip<T, FORM_ANY_N><<<grid, block, 0, s>>>(p))
     if (voxel_bytes == 1) VRT_LAUNCH_SKIP(uint8_t);
     else VRT_LAUNCH_SKIP(uint16_t);

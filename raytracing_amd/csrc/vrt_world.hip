@@ -393,9 +393,20 @@ __global__ __launch_bounds__(256) void k_column_vtops(const uint2 *masks, int nc
     tops0[(size_t)tcz * nc + tcx] = (uint16_t)v;
 }
 
-// The eight words of a cell: word = descending | negative x << 1 | negative z << 2.  One thread per cell and pair of
-// words (a quadrant of travel, negative x | negative z << 1), the four threads of a cell side by side: 64 bytes in a row.
-__global__ __launch_bounds__(256) void k_voxel_pyramid(int nc, int offcy, TopsLevels tl, uint4 *out)
+// The eight words of a cell: word = descending | negative x << 1 | negative z << 2, an entry per voxel level of the cell:
+// the empty box a ray that travels the word's way crosses from a voxel of that level -- BOX_NONE, or
+// (side - 1) << 8 | rise: the box spans `side` cells along x and z from the ray's own cell on in its direction of travel,
+// and along y from the voxel on for `rise` voxels more (BOX_RISE_ALL: up to the top of the window).  Two kinds of box
+// end up in that form, chosen here so that the traversal need not:
+//   the column square  2^L x 2^L cell columns with the cell's own at the corner, none of them with a solid voxel at or
+//                      above the window level (voxel's level - drop): rise = drop for a ray that descends, all the way
+//                      up for one that rises (valid inside a non-empty cell too, above its solid voxels);
+//   the octant cube    of the cell's record (side d cells, empty cells only): rise = what is left of the voxel's own
+//                      cell + 4 (d - 1).
+// The square is taken when twice its side exceeds the cube's (measured in the traversal, when it chose: better than once
+// and than four times).  One thread per cell and pair of words (a quadrant of travel, negative x | negative z << 1), the
+// four threads of a cell side by side: 64 bytes in a row.
+__global__ __launch_bounds__(256) void k_voxel_pyramid(int nc, int offcy, TopsLevels tl, uint4 *cells)
 {
     const int tx = blockIdx.x * 256 + threadIdx.x;
     const int tcx = tx >> 2, q = tx & 3;
@@ -404,6 +415,7 @@ __global__ __launch_bounds__(256) void k_voxel_pyramid(int nc, int offcy, TopsLe
     if (tcx >= nc) return;
     int wl = tcy - offcy;
     wl += wl < 0 ? nc : 0;
+    uint4 *cell = cells + CELL_U4 * (((size_t)tcz * nc + tcy) * nc + tcx);
     // the square of level L that extends towards -x has its corner 2^L - 1 columns before the cell
     const bool negx = (q & 1) != 0, negz = (q & 2) != 0;
     // Any level whose square lies at or below the voxel gives a valid box; two choices are kept.
@@ -411,8 +423,8 @@ __global__ __launch_bounds__(256) void k_voxel_pyramid(int nc, int offcy, TopsLe
     //   down[j]  the largest min(side, 4 * height above the square's top): a wide square with little room
     //            underneath ends a descending ray after a few voxels (measured with aligned blocks on the bench
     //            frame: 58 us against 62 us with the widest; factors 2..4 alike, 1 worse)
-    unsigned up[4] = {0, 0, 0, 0}, down[4] = {0, 0, 0, 0};
-    int      score[4] = {-1, -1, -1, -1};
+    int up_side[4] = {0, 0, 0, 0}, down_side[4] = {0, 0, 0, 0}, down_drop[4] = {0, 0, 0, 0};
+    int score[4] = {-1, -1, -1, -1};
     for (int L = 0; L <= tl.levels; ++L) {
         const int back = (1 << L) - 1;
         int x = negx ? tcx - back : tcx, z = negz ? tcz - back : tcz;
@@ -424,17 +436,32 @@ __global__ __launch_bounds__(256) void k_voxel_pyramid(int nc, int offcy, TopsLe
         for (int j = 0; j < 4; ++j) {
             const int v = 4 * wl + j;
             if (t > v) continue;
-            const unsigned e = ((unsigned)(L + 1) << 12) | (unsigned)min(v - t, 4095);
             const int sc = min(4 << L, 4 * (v - t + 1));
-            up[j] = e;
-            if (sc >= score[j]) { score[j] = sc; down[j] = e; }
+            up_side[j] = 1 << L;
+            if (sc >= score[j]) { score[j] = sc; down_side[j] = 1 << L; down_drop[j] = v - t; }
         }
     }
-    out[CELL_U4 * (((size_t)tcz * nc + tcy) * nc + tcx) + q] =
-        make_uint4(up[0] | (up[1] << 16), up[2] | (up[3] << 16), down[0] | (down[1] << 16), down[2] | (down[3] << 16));
+    // octant distances of the cell's record: byte o = sx | sy << 1 | sz << 2, bit set = positive direction
+    const uint2 dist = reinterpret_cast<const uint2 *>(cell)[1];
+    const int   oxz = (negx ? 0 : 1) | (negz ? 0 : 4);
+    const int   d_up = (int)(((oxz & 4 ? dist.y : dist.x) >> (8 * ((oxz | 2) & 3))) & 0xffu);
+    const int   d_down = (int)(((oxz & 4 ? dist.y : dist.x) >> (8 * (oxz & 3))) & 0xffu);
+    unsigned up[4], down[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        // (a side of 256 cells is stored as 255: the entry of a window-wide square that rises all the way must not read
+        // as BOX_NONE)
+        up[j] = 2 * up_side[j] > d_up ? ((unsigned)(min(up_side[j], 255) - 1) << 8) | BOX_RISE_ALL
+                : d_up > 0           ? ((unsigned)(d_up - 1) << 8) | (unsigned)((3 - j) + 4 * (d_up - 1))
+                                     : BOX_NONE;
+        down[j] = 2 * down_side[j] > d_down ? ((unsigned)(min(down_side[j], 255) - 1) << 8) | (unsigned)min(down_drop[j], (int)BOX_RISE_ALL - 1)
+                  : d_down > 0             ? ((unsigned)(d_down - 1) << 8) | (unsigned)(j + 4 * (d_down - 1))
+                                           : BOX_NONE;
+    }
+    cell[1 + q] = make_uint4(up[0] | (up[1] << 16), up[2] | (up[3] << 16), down[0] | (down[1] << 16), down[2] | (down[3] << 16));
 }
 
-hipError_t launch_build_voxel_pyramid(const uint8_t *planes, int nc, int offcy, uint16_t *tops, uint4 *out, hipStream_t s)
+hipError_t launch_build_voxel_pyramid(const uint8_t *planes, int nc, int offcy, uint16_t *tops, uint4 *cells, hipStream_t s)
 {
     const dim3 blockdim(256), grid2((nc + 63) / 64, (nc + 3) / 4);
     TopsLevels tl{};
@@ -448,7 +475,7 @@ hipError_t launch_build_voxel_pyramid(const uint8_t *planes, int nc, int offcy, 
         level = coarse;
         tl.tops[L] = level; tl.levels = L;
     }
-    k_voxel_pyramid<<<dim3((4 * nc + 255) / 256, nc, nc), blockdim, 0, s>>>(nc, offcy, tl, out);
+    k_voxel_pyramid<<<dim3((4 * nc + 255) / 256, nc, nc), blockdim, 0, s>>>(nc, offcy, tl, cells);
     return hipGetLastError();
 }
 

@@ -131,3 +131,54 @@ def test_control_flow_of_several_contexts_rehearsed_on_one_device(parts, monkeyp
     finally:
         for g in cores:
             g.close()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs in one process: RCCL between devices (never run by the build: its box has one)")
+def test_two_contexts_on_two_devices_gather_through_rccl():
+    """The path no one-GPU box can run: ncclCommInitAll over two devices, the peer's part through ncclSend / ncclRecv.
+    Two contexts, each with a replica of the world on its own device; vrt_gather of each context's own pose and
+    vrt_gather_strips / _bgr of one frame, compared with the same frames traced on the root alone."""
+    W, H, strip_h, n, parts = 640, 360, 16, 64, 2
+    p0 = Player.at((3.4, 20.7, -5.1), 0.6, -0.5)
+    wmin = scenes.window_min(p0.get_position(), n)
+    cores = [GraphicsCore(grid_n=n, voxel_format=VOXEL_PACKED_U8, trace_mode=TRACE_SKIP, device=r) for r in range(parts)]
+    try:
+        for g in cores:
+            g.generate_window(wmin)
+            g.reset_distance_field()
+        with sharding.Comm(cores) as comm:
+            stride = sharding.max_strip_rows(H, strip_h, parts) + 3
+            dev = [f"cuda:{r}" for r in range(parts)]
+            packed = [torch.zeros((stride, W, 4), dtype=torch.uint8, device=dev[r]) for r in range(parts)]
+            packed3 = [torch.zeros((stride, W, 3), dtype=torch.uint8, device=dev[r]) for r in range(parts)]
+            poses = [torch.zeros((H, W, 4), dtype=torch.uint8, device=dev[r]) for r in range(parts)]
+            gathered = torch.zeros((parts, stride, W, 4), dtype=torch.uint8, device=dev[0])
+            gathered3 = torch.zeros((parts, stride, W, 3), dtype=torch.uint8, device=dev[0])
+            frame, frame3, whole = (torch.zeros((H, W, 4), dtype=torch.uint8, device=dev[0]) for _ in range(3))
+            batch = torch.zeros((parts, H, W, 4), dtype=torch.uint8, device=dev[0])
+            for r in range(parts):
+                torch.cuda.synchronize(r)
+            for i in range(8):
+                cam = scenes.cam16(Player.at(p0.get_position(), 0.6 + 0.41 * i, -0.5))
+                cams = [scenes.cam16(Player.at(p0.get_position(), 0.6 + 0.41 * i + 0.2 * r, -0.45)) for r in range(parts)]
+                for r, g in enumerate(cores):
+                    g.trace_strips_device(cam, W, H, strip_h, r, parts, {"bgra8": packed[r].data_ptr()})
+                comm.gather_strips([t.data_ptr() for t in packed], gathered.data_ptr(), frame.data_ptr(), W * 4, H, strip_h, stride)
+                comm.gather_strips_bgr([t.data_ptr() for t in packed], [t.data_ptr() for t in packed3], gathered3.data_ptr(),
+                                       frame3.data_ptr(), W, H, strip_h, stride)
+                for r, g in enumerate(cores):
+                    g.trace_device(cams[r], W, H, 0, H, {"bgra8": poses[r].data_ptr()})
+                comm.gather([t.data_ptr() for t in poses], H * W * 4, batch.data_ptr())
+                for g in cores:
+                    g.sync()
+                cores[0].trace_device(cam, W, H, 0, H, {"bgra8": whole.data_ptr()})
+                cores[0].sync()
+                assert torch.equal(frame, whole), i
+                assert torch.equal(frame3, whole), i
+                for r in range(parts):
+                    cores[0].trace_device(cams[r], W, H, 0, H, {"bgra8": whole.data_ptr()})
+                    cores[0].sync()
+                    assert torch.equal(batch[r], whole), (i, r)
+    finally:
+        for g in cores:
+            g.close()

@@ -123,12 +123,15 @@ def test_index_updated_chunk_by_chunk_equals_an_index_built_whole(render_distanc
 
 
 @pytest.mark.parametrize("n,kind", [(64, "random"), (96, "terrain"), (160, "terrain")])
-def test_column_top_words_against_their_definition_in_numpy(n, kind):
-    """Every entry of the cells' column-top words, as downloaded, against the definition worked out here from the
-    voxels alone: entry (L + 1) << 12 | drop of voxel level v of a cell means that the square of 2^L x 2^L cell columns
-    with the cell's column at its corner, extending the way the word's rays travel, holds no solid voxel at or above
-    window level v - drop; rising words hold the widest such square, descending words the one with the largest
-    min(side in voxels, 4 * (drop + 1)), the wider of equals."""
+def test_box_words_against_their_definition_in_numpy(n, kind):
+    """Every entry of the cells' box words, as downloaded, against the definition worked out here from the voxels (and
+    the records' octant distances, which the parity tests cover): (side - 1) << 8 | rise, or 0xffff for none.  The column
+    square of level L -- 2^L x 2^L cell columns with the cell's own at the corner, extending the way the word's rays
+    travel -- is valid for a voxel of window level v when it holds no solid voxel at or above v - drop; rising words take
+    the widest valid square (rise 0xff: to the top of the window), descending words the one with the largest
+    min(side in voxels, 4 * (drop + 1)), the wider of equals (rise = drop, at most 254).  The octant cube of the record
+    (side d) takes its place unless twice the square's side exceeds d; its rise is what is left of the voxel's cell plus
+    4 (d - 1)."""
     rng = np.random.default_rng(11)
     pose = scenes.pose_b(9.3)
     wmin = scenes.window_min(pose.get_position(), n)
@@ -142,9 +145,10 @@ def test_column_top_words_against_their_definition_in_numpy(n, kind):
         g.upload_world(block)
         g.reset_distance_field()
         g.trace(scenes.cam16(pose), 64, 48, outputs=("bgra8",))   # levels the words for this camera's window
-        _, words = g.download_index(pyramid=True)
-    words = words.reshape(nc, nc, nc, 4, 2, 2).astype(np.int64)          # [tcz, tcy, tcx, quadrant, up/down, half]
+        records, words = g.download_index(pyramid=True)
+    words = words.reshape(nc, nc, nc, 4, 2, 2).astype(np.int64)          # [tcz, tcy, tcx, quadrant, rising/descending, half]
     entries = np.stack([words[..., 0] & 0xffff, words[..., 0] >> 16, words[..., 1] & 0xffff, words[..., 1] >> 16], -1)  # [..., j]
+    dist = records[:, 2:4].copy().view(np.uint8).reshape(nc, nc, nc, 8).astype(np.int64)   # byte o = sx | sy << 1 | sz << 2
     # window level of every texel row: texel = rem_euclid(world, n), world = wmin + level
     off = int(wmin[1]) % n
     solid = np.roll(block != 0, -off, axis=1)                              # [tz, level, tx]
@@ -157,21 +161,29 @@ def test_column_top_words_against_their_definition_in_numpy(n, kind):
         tables.append(np.maximum(t, np.roll(t, -h, axis=0)))
     offc = off // 4
     wl = (np.arange(nc) - offc) % nc                                       # window layer of torus cell row tcy
+    j = np.arange(4)[None, None, None, :]
     for q in range(4):
         negx, negz = q & 1, q >> 1
-        up = np.zeros((nc, nc, nc, 4), np.int64)
-        down = np.zeros((nc, nc, nc, 4), np.int64)
+        up_side = np.zeros((nc, nc, nc, 4), np.int64)
+        down_side = np.zeros((nc, nc, nc, 4), np.int64)
+        down_drop = np.zeros((nc, nc, nc, 4), np.int64)
         score = np.full((nc, nc, nc, 4), -1, np.int64)
-        v = (4 * wl[None, :, None, None] + np.arange(4)[None, None, None, :])
+        v = 4 * wl[None, :, None, None] + j
         for L, t in enumerate(tables):
             back = (1 << L) - 1
             tq = np.roll(t, (back if negz else 0, back if negx else 0), axis=(0, 1))[:, None, :, None]   # [tcz, 1, tcx, 1]
             ok = tq <= v
-            e = ((L + 1) << 12) | np.minimum(v - tq, 4095)
             sc = np.minimum(4 << L, 4 * (v - tq + 1))
-            up = np.where(ok, e, up)
+            up_side = np.where(ok, 1 << L, up_side)
             better = ok & (sc >= score)
-            down = np.where(better, e, down)
+            down_side = np.where(better, 1 << L, down_side)
+            down_drop = np.where(better, v - tq, down_drop)
             score = np.where(better, sc, score)
+        o = (0 if negx else 1) | (0 if negz else 4)
+        d_up, d_down = dist[..., o | 2][..., None], dist[..., o][..., None]
+        up = np.where(2 * up_side > d_up, ((np.minimum(up_side, 255) - 1) << 8) | 0xff,
+                      np.where(d_up > 0, ((d_up - 1) << 8) | ((3 - j) + 4 * (d_up - 1)), 0xffff))
+        down = np.where(2 * down_side > d_down, ((np.minimum(down_side, 255) - 1) << 8) | np.minimum(down_drop, 254),
+                        np.where(d_down > 0, ((d_down - 1) << 8) | (j + 4 * (d_down - 1)), 0xffff))
         assert np.array_equal(entries[:, :, :, q, 0, :], up), (q, "rising")
         assert np.array_equal(entries[:, :, :, q, 1, :], down), (q, "descending")

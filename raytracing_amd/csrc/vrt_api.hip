@@ -151,7 +151,8 @@ struct vrt_ctx {
     bool        have_world   = false;
     // skip structure
     uint4      *d_cells      = nullptr;  // (n/4)^3 x 128 B: per cell the record (occupancy mask + octant distances), then its column-top words
-    uint16_t   *d_tops       = nullptr;  // column-top tables (build scratch), TOPS_LEVELS * (n/4)^2
+    uint16_t   *d_tops       = nullptr;  // column-top tables (build scratch), TOPS_LEVELS * (n/4)^2, and behind them d_sky
+    uint32_t   *d_sky        = nullptr;  // window level just above the highest solid voxel of the window (TraceParams::sky)
     uint4      *d_pyr        = nullptr;  // d_cells + 1: column-top words at voxel precision, cell i's from d_pyr[CELL_U4 * i]
     uint8_t    *d_build      = nullptr;  // 14 x (n/4)^3 B: the cells' masks side by side and the x and y planes of the octant distance transform, kept between builds
     // what the skip structure has not seen yet: nothing (skip_valid), a box of regenerated chunks, or everything
@@ -181,7 +182,7 @@ struct vrt_ctx {
     //                       and binning the workgroup's rays in LDS (same outputs; for A/B measurements)
     uint32_t    knob_tile_log2h = 2;
     uint32_t    knob_tile_lanes = 0;     // VRT_TILE_LANES=32|64: lanes of a wavefront that trace (0: the library chooses per launch)
-    bool        knob_no_row_order = false, knob_sched_debug = false, knob_secondary_binned = true;
+    bool        knob_no_row_order = false, knob_sched_debug = false, knob_secondary_binned = true, knob_no_sky = false;
     int32_t     knob_row_block0 = -1;
     // staging for host-resident outputs
     void       *d_stage      = nullptr;
@@ -268,7 +269,11 @@ int ensure_skip_structure(vrt_ctx *c, int offcy)
     if (work) { int rc = join_lanes(c); if (rc != VRT_OK) return rc; }  // no trace reads the index while it is rewritten
     if (!c->skip_valid) {
         if (!c->d_cells) { HIP_TRY(hipMalloc(&c->d_cells, cells(c) * vrt::CELL_U4 * sizeof(uint4))); c->d_pyr = c->d_cells + 1; }
-        if (!c->d_tops) HIP_TRY(hipMalloc(&c->d_tops, (size_t)vrt::TOPS_LEVELS * (c->n / 4) * (c->n / 4) * sizeof(uint16_t)));
+        if (!c->d_tops) {
+            const size_t tables = (size_t)vrt::TOPS_LEVELS * (c->n / 4) * (c->n / 4) * sizeof(uint16_t);  // (a multiple of 4: n / 4 is even)
+            HIP_TRY(hipMalloc(&c->d_tops, tables + 64));
+            c->d_sky = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(c->d_tops) + tables);
+        }
         if (!c->d_build) HIP_TRY(hipMalloc(&c->d_build, vrt::PLANE_BYTES_PER_CELL * cells(c)));
         const int nc = (int)c->n / 4;
         if (c->index_built && c->dirty_box) {
@@ -291,7 +296,7 @@ int ensure_skip_structure(vrt_ctx *c, int offcy)
         c->pyr_offcy = -1;
     }
     if (offcy >= 0 && c->pyr_offcy != offcy) {
-        HIP_TRY(vrt::launch_build_voxel_pyramid(c->d_build, (int)c->n / 4, offcy, c->d_tops, c->d_cells, c->stream));
+        HIP_TRY(vrt::launch_build_voxel_pyramid(c->d_build, (int)c->n / 4, offcy, c->d_tops, c->d_cells, c->d_sky, c->stream));
         c->pyr_offcy = offcy;
     }
     if (work) return fork_lanes(c);
@@ -471,7 +476,11 @@ int prepare_trace(vrt_ctx *c, Scratch &S, hipStream_t st, bool may_build, const 
         p.off[k] = r < 0 ? r + n : r;
         p.a0[k] = (int)std::floor(cam[12 + k]);  // |position| <= 2^20 was checked above
         p.thr0[k] = 0.5f - VRT_MARGIN * (std::fabs(cam[12 + k]) + 1.0f);  // (this file is built without contraction, like the kernels)
+        // a ray leaves the loaded area into voxel lo + n - 2 (towards +) or lo (towards -): through planes lo + n - 2, lo + 1
+        p.sky_pos[k] = (float)(p.lo[k] + n - 2) - cam[12 + k];
+        p.sky_neg[k] = (float)(p.lo[k] + 1) - cam[12 + k];
     }
+    p.sky = use_skip && !c->knob_no_sky ? c->d_sky : nullptr;
     p.block = c->d_block;
     p.dist = c->dist_nonzero ? c->d_dist : nullptr;
     p.cells = c->d_cells; p.nc = (int)c->n / 4; p.pyr = c->d_pyr;
@@ -608,6 +617,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out)
     if (const char *v = std::getenv("VRT_NO_ROW_ORDER")) c->knob_no_row_order = v[0] == '1';
     if (const char *v = std::getenv("VRT_ROW_BLOCK0")) c->knob_row_block0 = std::atoi(v);
     if (const char *v = std::getenv("VRT_SCHED_DEBUG")) c->knob_sched_debug = v[0] == '1';
+    if (const char *v = std::getenv("VRT_NO_SKY")) c->knob_no_sky = v[0] == '1';
     if (const char *v = std::getenv("VRT_SECONDARY")) c->knob_secondary_binned = std::strcmp(v, "pixel") != 0;
     auto bail = [&](int code) { vrt_destroy(c); return code; };
 #define TRY_OR_BAIL(expr)                                                                                     \

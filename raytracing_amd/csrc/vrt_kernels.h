@@ -94,6 +94,13 @@ struct TraceParams {
     // record.  Window levels are counted from the bottom of the loaded window, so the words are rebuilt when the window's
     // vertical offset changes, and whenever records change.
     const uint4 *pyr;           // cells + 1
+    // Rays that cannot hit anything.  *sky = the window level just above the highest solid voxel of the whole window (written
+    // with the box words; null: not known, or the launch wants it left alone): a ray that rises from a camera at or above
+    // that level meets air only, and all its pixel needs is whether the ray left the window after 1000 iterations or more
+    // (raytrace.glsl:73-75).  sky_pos / sky_neg: per axis the plane through which a ray that travels towards + / - leaves
+    // the loaded area (raytrace.glsl:19-24), less the camera's position -- the numerators of the exit parameters.
+    const uint32_t *sky;
+    float    sky_pos[3], sky_neg[3];
     // per-frame tables (device memory, filled by launch_frame_tables with the kernels' own arithmetic;
     // null = evaluate in place): the two divisions of raytrace.glsl:121 per column / per row, and the
     // sine of raytrace.glsl:131 for every voxel coordinate a hit point can floor to
@@ -138,7 +145,8 @@ hipError_t launch_update_cells(const void *block, int voxel_bytes, int n, uint4 
                                const int extent[3], hipStream_t s);
 // planes and cells: as launch_build_cells left them (the masks and the records' distances are read); tops: scratch of at least
 // TOPS_LEVELS * nc * nc uint16_t; offcy = rem_euclid(lower_y, n) / 4; writes the box words of every cell (cells[CELL_U4 * i + 1 .. + 4])
-hipError_t launch_build_voxel_pyramid(const uint8_t *planes, int nc, int offcy, uint16_t *tops, uint4 *cells, hipStream_t s);
+// and *sky, the window level just above the highest solid voxel of all (TraceParams::sky)
+hipError_t launch_build_voxel_pyramid(const uint8_t *planes, int nc, int offcy, uint16_t *tops, uint4 *cells, uint32_t *sky, hipStream_t s);
 hipError_t launch_frame_tables(float *ncx, float *ncy, float *sin2, uint32_t w, uint32_t h, float ncy_off,
                                const int32_t sin_base[3], uint32_t sin_len, hipStream_t s);
 // dst[i * part + j] = src[CELL_U4 * i + j], j < part: the records (src = cells, part = 1) or the column-top words

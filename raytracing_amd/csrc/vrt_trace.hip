@@ -1091,6 +1091,39 @@ __device__ __attribute__((noinline)) unsigned degenerate_pixel(const TraceParams
     return H.work;
 }
 
+// Camera rays that can meet nothing but air: the camera's voxel lies at or above the level of the highest solid voxel of
+// the whole window (*P.sky, written with the box words) and the ray rises.  Such a ray ends where it leaves the loaded
+// area, a miss, and its pixel depends on one thing only: whether it got there in 1000 iterations or more
+// (raytrace.glsl:73-75).  An iteration is a step of one voxel along one axis, so the count is the sum over the axes of
+// the distance between the start voxel and the last one; here it is taken from the exit point worked out with
+// approximate reciprocals -- off by at most one voxel per axis (where the exit point rounds to, which plane the
+// reference's own rounding puts first) -- and only trusted when it is not within 6 of 1000.  Wave uniform: true when
+// every lane of the wavefront has such a ray and a trusted count (H is then the ray's result, with that count); any
+// other wavefront traces its rays as usual.  Not used when the launch writes the planes that need the last voxel or the
+// count itself.
+VRT_DEV bool sky_miss(const TraceParams &P, bool regular, float rdx, float rdy, float rdz, RayHit &H)
+{
+    if (P.sky == nullptr || P.voxel != nullptr || P.steps != nullptr) return false;
+    if (P.a0[1] - P.lo[1] < (int)*P.sky) return false;
+    const bool rises = regular && rdy > 0.0f;
+    if (__builtin_amdgcn_ballot_w64(rises) != __builtin_amdgcn_ballot_w64(true)) return false;
+    const float tx = (rdx > 0.0f ? P.sky_pos[0] : P.sky_neg[0]) * __builtin_amdgcn_rcpf(rdx);
+    const float ty = P.sky_pos[1] * __builtin_amdgcn_rcpf(rdy);
+    const float tz = (rdz > 0.0f ? P.sky_pos[2] : P.sky_neg[2]) * __builtin_amdgcn_rcpf(rdz);
+    const float t = __builtin_fminf(__builtin_fminf(tx, ty), tz);
+    const int   ex = f2i_floor(__builtin_fmaf(rdx, t, P.m[12])), ey = f2i_floor(__builtin_fmaf(rdy, t, P.m[13])),
+                ez = f2i_floor(__builtin_fmaf(rdz, t, P.m[14]));
+    // (|a - b| of signed coordinates by the unsigned instruction: both moved up by 2^31, which keeps their order)
+    const unsigned up = 0x80000000u;
+    const unsigned steps = __sad((unsigned)ez ^ up, (unsigned)P.a0[2] ^ up, __sad((unsigned)ey ^ up, (unsigned)P.a0[1] ^ up,
+                                 __sad((unsigned)ex ^ up, (unsigned)P.a0[0] ^ up, 0u)));
+    const bool unsure = steps - 994u <= 12u;  // 994 .. 1006
+    if (__builtin_amdgcn_ballot_w64(unsure) != 0) return false;
+    H.hit = 0; H.capped = 0; H.vx = H.vy = H.vz = 0; H.k = 0; H.sk = 0; H.steps = steps; H.iters = 0; H.work = 0; H.block_id = 0;
+    H.t = -1.0f; H.hx = H.hy = H.hz = 0.0f;
+    return true;
+}
+
 // (eight wavefronts per SIMD, i.e. at most 64 VGPRs: measured 1.8 % faster than the 65 the compiler takes unasked)
 template <typename T, int FORM>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_trace_skip(const TraceParams P)
@@ -1114,7 +1147,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         // loaded area (raytrace.glsl:19-24), evaluated once per frame on the host
         const int lox = P.lo[0], loy = P.lo[1], loz = P.lo[2], upx = P.up[0], upy = P.up[1], upz = P.up[2];
         RayHit H;
-        if (regular) {
+        const bool sky = FORM != FORM_CAPPED && sky_miss(P, regular, rdx, rdy, rdz, H);  // (wave uniform)
+        if (regular && !sky) {
             if (FORM == FORM_CAPPED) traverse_skip<T>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, upx, upy, upz, H);
             else traverse_cells_regular<T, pow2_of(FORM), true>(P, rox, roy, roz, rdx, rdy, rdz, lox, loy, loz, H);
             work = H.work;

@@ -461,13 +461,26 @@ __global__ __launch_bounds__(256) void k_voxel_pyramid(int nc, int offcy, TopsLe
     cell[1 + q] = make_uint4(up[0] | (up[1] << 16), up[2] | (up[3] << 16), down[0] | (down[1] << 16), down[2] | (down[3] << 16));
 }
 
-hipError_t launch_build_voxel_pyramid(const uint8_t *planes, int nc, int offcy, uint16_t *tops, uint4 *cells, hipStream_t s)
+// the highest of all column tops (one workgroup)
+__global__ __launch_bounds__(256) void k_tops_max(const uint16_t *tops0, int count, uint32_t *out)
+{
+    __shared__ unsigned part[4];
+    unsigned v = 0;
+    for (int i = (int)threadIdx.x; i < count; i += 256) v = max(v, (unsigned)tops0[i]);
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o));
+    if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = max(max(part[0], part[1]), max(part[2], part[3]));
+}
+
+hipError_t launch_build_voxel_pyramid(const uint8_t *planes, int nc, int offcy, uint16_t *tops, uint4 *cells, uint32_t *sky, hipStream_t s)
 {
     const dim3 blockdim(256), grid2((nc + 63) / 64, (nc + 3) / 4);
     TopsLevels tl{};
     uint16_t *level = tops;
     k_column_vtops<<<grid2, blockdim, 0, s>>>(reinterpret_cast<const uint2 *>(planes), nc, offcy, level);
     tl.tops[0] = level; tl.levels = 0;
+    k_tops_max<<<1, blockdim, 0, s>>>(level, nc * nc, sky);
     for (int L = 1; L < TOPS_LEVELS; ++L) {
         if ((1 << L) > nc) break;
         uint16_t *coarse = level + (size_t)nc * nc;

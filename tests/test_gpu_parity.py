@@ -288,6 +288,32 @@ def test_thousand_step_misses_are_teal():
         assert_planes_equal(got, want, "teal")
 
 
+def test_frame_only_launches_over_sky_match_the_oracle():
+    """A launch that writes neither the voxel nor the steps plane lets a wavefront whose 64 rays rise from a camera above
+    every solid voxel skip the traversal: its pixels are black, or teal where the ray leaves the window after 1000
+    iterations or more, and the kernel takes that count from the exit point unless it comes within 6 of 1000.  A floor
+    under a camera in a 704^3 window: the teal region's edge crosses the frame; cameras at, just above and below the
+    floor's top, looking up and along the diagonals; every plane such a launch writes, against the oracle."""
+    n = 704
+    block = np.zeros((n, n, n), np.uint8)
+    block[:, 404, :] = 1          # a floor at world y = -300
+    block[300:340, 405:440, 100:130] = 1   # and a tower on it, up to world y = -265
+    world = O.World(block)
+    planes = ("bgra8", "rgba", "face", "t", "hit_point")
+    both = False
+    with core_for(block, TRACE_SKIP) as g:
+        for pos, yaw, pitch in [((16.5, 16.5, 16.5), -0.7853981, 0.6155), ((16.5, 16.5, 16.5), 2.3, 0.45), ((3.2, -263.7, 29.9), 0.4, 0.9),
+                                ((3.2, -265.5, 29.9), 0.4, 0.3), ((3.2, -299.5, 29.9), -2.0, 0.2), ((20.1, 8.8, 2.2), 1.1, -0.1),
+                                ((20.1, 8.8, 2.2), 1.1, 1.4), ((0.5, 31.5, 0.5), -0.78, 0.62), ((31.5, 0.5, 31.5), 2.36, 0.6)]:
+            cam = scenes.cam16(Player.at(pos, yaw, pitch))
+            want = O.trace(world, cam, 256, 144)
+            got = g.trace(cam, 256, 144, outputs=planes)
+            assert_planes_equal(got, {k: want[k] for k in planes}, f"frame only, pos {pos} yaw {yaw} pitch {pitch}")
+            miss = want["face"] == -1
+            both = both or bool(((want["steps"] >= 1000) & miss).any() and ((want["steps"] < 1000) & miss).any())
+        assert both  # (some pose sees both colours of sky)
+
+
 def test_nonzero_distance_image_takes_the_literal_kernel():
     rng = np.random.default_rng(11)
     n = 64

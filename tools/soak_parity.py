@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Long parity run (not part of pytest): many random poses over the procedural terrain, full frames,
-every output plane of the HIP skip kernel against the CPU oracle, bit for bit.
+every output plane of the HIP skip kernel against the CPU oracle, bit for bit, and the planes of a second launch that
+asks for the frame without the voxel and steps planes (the launch a host makes; wavefronts of sky take a short cut there).
 usage: soak_parity.py [poses per world, default 40] [seed] [default|odd|sparse|axis]   -> one summary line per world + total
 (axis: the default worlds seen along the axes -- yaw and pitch within 1e-3 of multiples of pi/2, often exactly on them, and
 positions with integer coordinates: direction components that are zero, or 1e-8, and plane parameters up to 1e11)"""
@@ -63,6 +64,16 @@ for n, fmt, dtype, w, h in WORLDS[kind]:
                 if d:
                     bad += d
                     print(f"MISMATCH n={n} pose {i} plane {k}: {d} elements, pos={pos.tolist()} look={p.look_direction}", flush=True)
+            # the frame alone: a launch that writes neither the voxel nor the steps plane lets wavefronts whose rays can
+            # only meet air skip the traversal (the pixel needs no more than "1000 iterations or not")
+            alone = g.trace(cam, w, h, outputs=("bgra8", "rgba", "face", "t"))
+            for k in alone:
+                a, b = alone[k], want[k]
+                if a.dtype == np.float32: a, b = a.view(np.uint32), b.view(np.uint32)
+                d = int((a != b).sum())
+                if d:
+                    bad += d
+                    print(f"MISMATCH n={n} pose {i} plane {k} of the frame-only launch: {d} elements, pos={pos.tolist()} look={p.look_direction}", flush=True)
             px += w * h
             if i % 10 == 9: print(f"  n={n}: {i + 1} poses, {bad} mismatching elements, {time.time() - t_start:.0f} s", flush=True)
         print(f"world n={n} {w}x{h}: {poses} poses, {px} pixels, {len(PLANES)} planes each, mismatching elements: {bad}", flush=True)

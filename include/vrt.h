@@ -80,7 +80,7 @@ typedef struct vrt_outputs {
 } vrt_outputs;
 
 /* Measurement knobs, read from the environment once per vrt_create and meant for A/B runs only (none changes a
- * pixel): VRT_TILE_LOG2H=k (wavefront tile of (64 >> k) x (1 << k) pixels instead of 16 x 4), VRT_NO_ROW_ORDER=1
+ * pixel): VRT_TILE_LOG2H=k (wavefront tile of (64 >> k) x (1 << k) pixels instead of 32 x 2), VRT_NO_ROW_ORDER=1
  * (workgroup rows always top to bottom), VRT_ROW_BLOCK0=r (always start at workgroup row r), VRT_SCHED_DEBUG=1
  * (print what each launch measured; synchronises), VRT_SECONDARY=pixel (vrt_trace_secondary without the LDS
  * binning); vrt_comm_create reads VRT_COMM_SELF_SENDRECV=1 (the root's own part through RCCL as well). */

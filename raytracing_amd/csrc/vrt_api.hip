@@ -174,13 +174,13 @@ struct vrt_ctx {
     bool        skip_valid   = false;
     uint32_t   *d_flag       = nullptr;
     // measurement knobs, read from the environment once, when the context is created
-    //   VRT_TILE_LOG2H=k    wave tile of (64 >> k) x (1 << k) pixels instead of 16 x 4
+    //   VRT_TILE_LOG2H=k    wave tile of (64 >> k) x (1 << k) pixels instead of 32 x 2
     //   VRT_NO_ROW_ORDER=1  workgroup rows always top to bottom
     //   VRT_ROW_BLOCK0=r    workgroup rows always start at row block r
     //   VRT_SCHED_DEBUG=1   print what each launch measured for the dispatch order (synchronises)
     //   VRT_SECONDARY=pixel vrt_trace_secondary runs every pixel's rays on the pixel's own lane instead of staging
     //                       and binning the workgroup's rays in LDS (same outputs; for A/B measurements)
-    uint32_t    knob_tile_log2h = 2;
+    uint32_t    knob_tile_log2h = 1;
     uint32_t    knob_tile_lanes = 0;     // VRT_TILE_LANES=32|64: lanes of a wavefront that trace (0: the library chooses per launch)
     bool        knob_no_row_order = false, knob_sched_debug = false, knob_secondary_binned = true, knob_no_sky = false;
     int32_t     knob_row_block0 = -1;

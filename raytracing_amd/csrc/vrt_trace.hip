@@ -389,6 +389,9 @@ VRT_DEV void traverse_skip(const TraceParams &P, float rox, float roy, float roz
 // whose ray is live, finish() turns the end state into the reference's outputs.  traverse_cells
 // below runs one ray per lane to the end; the stream kernel keeps lanes busy by starting a new ray
 // in a lane whose ray has ended.
+#ifndef VRT_WALK_STEPS
+#define VRT_WALK_STEPS 2  // unit steps per trip of a lane without a box (measured: 1, 3, 4 and 6 are no better)
+#endif
 // POW2: 0 = any grid (texel wrap by subtraction, 64-bit cell addresses); 1 = power-of-two grid up to 1024 (wrap by bit
 // fields, 32-bit byte offsets); 2 = power-of-two grid above that (bit fields, 64-bit byte offsets)
 template <typename T, int POW2>
@@ -647,7 +650,7 @@ struct CellRay {
             // ---- phase B: a few unit steps through the non-empty cell(s)
             // change of the mask bit index (z*16 + y*4 + x of the unmirrored voxel) per unit step
             const int dbx = 1 | smx, dby = 4 ^ (smy & ~7), dbz = 16 ^ (smz & ~31);  // +-1, +-4, +-16
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < VRT_WALK_STEPS; ++i) {
 #ifdef VRT_DIAG_ITERS
                 iters += 0x10000u;
 #endif

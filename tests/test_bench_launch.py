@@ -106,7 +106,7 @@ def test_counter_record_the_bench_prices_is_complete():
         assert 0.5 < c["lanes_active_per_vector_instruction"] <= 1.0
         assert 0.0 < c["l1_hit_rate"] <= 1.0 and 0.0 < c["l2_hit_rate"] <= 1.0
         assert 0.0 < c["issue_wait_fraction_of_wave_cycles"] < 1.0 and 0.0 < c["memory_wait_fraction_of_wave_cycles"] < 1.0
-        assert c["waves"] == 32640
+        assert c["waves"] == 32400   # 60 x 540 wavefront tiles of 32 x 2 pixels
     assert 0.9 < t["skip_plain_order_valu_instructions"] / t["skip_valu_instructions"] < 1.0
 
 

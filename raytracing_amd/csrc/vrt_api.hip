@@ -184,6 +184,8 @@ struct vrt_ctx {
     uint32_t    knob_tile_lanes = 0;     // VRT_TILE_LANES=32|64: lanes of a wavefront that trace (0: the library chooses per launch)
     bool        knob_no_row_order = false, knob_sched_debug = false, knob_secondary_binned = true, knob_no_sky = false;
     int32_t     knob_row_block0 = -1;
+    float       knob_sky_reach = 0.6f;   // VRT_SKY_REACH=f: a descending ray is tried for the sky short cut when it would lose less than the
+                                         // camera's height above the highest solid voxel over f * n voxels of path
     // staging for host-resident outputs
     void       *d_stage      = nullptr;
     size_t      stage_bytes  = 0;
@@ -481,6 +483,7 @@ int prepare_trace(vrt_ctx *c, Scratch &S, hipStream_t st, bool may_build, const 
         p.sky_neg[k] = (float)(p.lo[k] + 1) - cam[12 + k];
     }
     p.sky = use_skip && !c->knob_no_sky ? c->d_sky : nullptr;
+    p.sky_slope = 1.0f / (c->knob_sky_reach * (float)c->n);
     p.block = c->d_block;
     p.dist = c->dist_nonzero ? c->d_dist : nullptr;
     p.cells = c->d_cells; p.nc = (int)c->n / 4; p.pyr = c->d_pyr;
@@ -618,6 +621,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out)
     if (const char *v = std::getenv("VRT_ROW_BLOCK0")) c->knob_row_block0 = std::atoi(v);
     if (const char *v = std::getenv("VRT_SCHED_DEBUG")) c->knob_sched_debug = v[0] == '1';
     if (const char *v = std::getenv("VRT_NO_SKY")) c->knob_no_sky = v[0] == '1';
+    if (const char *v = std::getenv("VRT_SKY_REACH")) { const float f = (float)std::atof(v); if (f >= 0.05f && f <= 100.0f) c->knob_sky_reach = f; }
     if (const char *v = std::getenv("VRT_SECONDARY")) c->knob_secondary_binned = std::strcmp(v, "pixel") != 0;
     auto bail = [&](int code) { vrt_destroy(c); return code; };
 #define TRY_OR_BAIL(expr)                                                                                     \
@@ -1019,7 +1023,10 @@ int vrt_download_index(vrt_ctx *c, void *cells_out, void *pyr_out, uint32_t memo
     if (c->dist_nonzero) return fail(VRT_E_UNSUPPORTED, "a world with a non-zero distance image has no traversal index");
     HIP_TRY(hipSetDevice(c->device));
     { int rc = ensure_skip_structure(c, -1); if (rc != VRT_OK) return rc; }
-    if (pyr_out && c->pyr_offcy < 0) return fail(VRT_E_UNSUPPORTED, "the column-top pyramid is levelled by the first trace after a world change");
+    if (pyr_out && c->pyr_offcy < 0) return fail(VRT_E_UNSUPPORTED, "the box words are levelled by the first trace after a world change");
+    // (the cells, records included, are written together with the box words: before the first trace, for a window at the
+    // bottom of the torus; the next trace levels the words for its own window)
+    if (c->pyr_offcy < 0) { int rc = ensure_skip_structure(c, 0); if (rc != VRT_OK) return rc; }
     // 16 (the record) and 64 (the column-top words) of every 128 bytes: gathered by a kernel, into the caller's device
     // memory or into a staging buffer
     void *stage = nullptr;

@@ -18,7 +18,7 @@ constexpr unsigned CELL_SHIFT = 7;  // log2 of its bytes
 constexpr unsigned PYR_U4 = 4;      // uint4 units of column-top words per cell, from cells[CELL_U4 * i + 1]
 constexpr unsigned BOX_NONE = 0xffffu;   // entry of a box word: no empty box known, the ray steps voxel by voxel
 constexpr unsigned BOX_RISE_ALL = 0xffu;  // ... its rise field: up to the top of the window
-constexpr unsigned PLANE_BYTES_PER_CELL = 14;  // launch_build_cells' planes: masks 8, x planes 2, y planes 4
+constexpr unsigned PLANE_BYTES_PER_CELL = 22;  // launch_build_cells' planes: masks 8, octant distances 8, x planes 2, y planes 4
 constexpr int      TOPS_LEVELS = 9; // tables of column tops: squares of 1, 2, .. 256 cell columns
 
 // Records the thread's error message (vrt_last_error) and returns `code`; shared by the files of the C ABI.
@@ -95,12 +95,13 @@ struct TraceParams {
     // vertical offset changes, and whenever records change.
     const uint4 *pyr;           // cells + 1
     // Rays that cannot hit anything.  *sky = the window level just above the highest solid voxel of the whole window (written
-    // with the box words; null: not known, or the launch wants it left alone): a ray that rises from a camera at or above
-    // that level meets air only, and all its pixel needs is whether the ray left the window after 1000 iterations or more
-    // (raytrace.glsl:73-75).  sky_pos / sky_neg: per axis the plane through which a ray that travels towards + / - leaves
+    // with the box words; null: not known, or the launch wants it left alone): a ray that stays at or above that level
+    // meets air only, and all its pixel needs is whether the ray left the window after 1000 iterations or more
+    // (raytrace.glsl:73-75; sky_miss in vrt_trace.hip).  sky_pos / sky_neg: per axis the plane through which a ray that travels towards + / - leaves
     // the loaded area (raytrace.glsl:19-24), less the camera's position -- the numerators of the exit parameters.
     const uint32_t *sky;
     float    sky_pos[3], sky_neg[3];
+    float    sky_slope;   // 1 / (0.6 n): levels a ray may lose per voxel of path, per level of room, and still be worth the test
     // per-frame tables (device memory, filled by launch_frame_tables with the kernels' own arithmetic;
     // null = evaluate in place): the two divisions of raytrace.glsl:121 per column / per row, and the
     // sine of raytrace.glsl:131 for every voxel coordinate a hit point can floor to

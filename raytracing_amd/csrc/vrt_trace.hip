@@ -1094,24 +1094,29 @@ __device__ __attribute__((noinline)) unsigned degenerate_pixel(const TraceParams
     return H.work;
 }
 
-// Camera rays that can meet nothing but air: the camera's voxel lies at or above the level of the highest solid voxel of
-// the whole window (*P.sky, written with the box words) and the ray rises.  Such a ray ends where it leaves the loaded
-// area, a miss, and its pixel depends on one thing only: whether it got there in 1000 iterations or more
-// (raytrace.glsl:73-75).  An iteration is a step of one voxel along one axis, so the count is the sum over the axes of
-// the distance between the start voxel and the last one; here it is taken from the exit point worked out with
-// approximate reciprocals -- off by at most one voxel per axis (where the exit point rounds to, which plane the
-// reference's own rounding puts first) -- and only trusted when it is not within 6 of 1000.  Wave uniform: true when
-// every lane of the wavefront has such a ray and a trusted count (H is then the ray's result, with that count); any
-// other wavefront traces its rays as usual.  Not used when the launch writes the planes that need the last voxel or the
-// count itself.
+// Camera rays that can meet nothing but air.  *P.sky is the level of the highest solid voxel of the whole window, plus one
+// (written with the box words): a ray whose every voxel lies at or above that level ends where it leaves the loaded area,
+// a miss, and its pixel depends on one thing only: whether it got there in 1000 iterations or more (raytrace.glsl:73-75).
+// A ray that rises from a camera at or above that level is such a ray; so is one that descends but leaves the loaded
+// area while still two levels above it (a ray's lowest voxel is its last one).  An iteration is a step of one voxel along
+// one axis, so the count is the sum over the axes of the distance between the start voxel and the last one; here the
+// last voxel is taken from the exit point worked out with approximate reciprocals -- off by at most one voxel per axis
+// (where the exit point rounds to, which plane the reference's own rounding puts first), hence the two levels of margin
+// -- and the count is only trusted when it is not within 6 of 1000.  Wave uniform: true when every lane of the
+// wavefront has such a ray and a trusted count (H is then the ray's result, with that count); any other wavefront
+// traces its rays as usual, and a wavefront with a ray too steep to stay above the highest voxel as far as the loaded
+// area reaches does not try.  Not used when the launch writes the planes that need the last voxel or the count itself.
 VRT_DEV bool sky_miss(const TraceParams &P, bool regular, float rdx, float rdy, float rdz, RayHit &H)
 {
     if (P.sky == nullptr || P.voxel != nullptr || P.steps != nullptr) return false;
-    if (P.a0[1] - P.lo[1] < (int)*P.sky) return false;
-    const bool rises = regular && rdy > 0.0f;
-    if (__builtin_amdgcn_ballot_w64(rises) != __builtin_amdgcn_ballot_w64(true)) return false;
+    const int top = (int)*P.sky, room = (P.a0[1] - P.lo[1]) - top;  // levels between the camera's voxel and the highest solid one
+    if (room < 0) return false;
+    // (a ray from the middle of the loaded area leaves it after 0.5 n to 0.9 n voxels: one that loses more than `room`
+    // levels over 0.6 n may as well not be looked at)
+    const float steepest = -(float)room * P.sky_slope;
+    if (__builtin_amdgcn_ballot_w64(regular && rdy > steepest) != __builtin_amdgcn_ballot_w64(true)) return false;
     const float tx = (rdx > 0.0f ? P.sky_pos[0] : P.sky_neg[0]) * __builtin_amdgcn_rcpf(rdx);
-    const float ty = P.sky_pos[1] * __builtin_amdgcn_rcpf(rdy);
+    const float ty = (rdy > 0.0f ? P.sky_pos[1] : P.sky_neg[1]) * __builtin_amdgcn_rcpf(rdy);
     const float tz = (rdz > 0.0f ? P.sky_pos[2] : P.sky_neg[2]) * __builtin_amdgcn_rcpf(rdz);
     const float t = __builtin_fminf(__builtin_fminf(tx, ty), tz);
     const int   ex = f2i_floor(__builtin_fmaf(rdx, t, P.m[12])), ey = f2i_floor(__builtin_fmaf(rdy, t, P.m[13])),
@@ -1121,7 +1126,8 @@ VRT_DEV bool sky_miss(const TraceParams &P, bool regular, float rdx, float rdy, 
     const unsigned steps = __sad((unsigned)ez ^ up, (unsigned)P.a0[2] ^ up, __sad((unsigned)ey ^ up, (unsigned)P.a0[1] ^ up,
                                  __sad((unsigned)ex ^ up, (unsigned)P.a0[0] ^ up, 0u)));
     const bool unsure = steps - 994u <= 12u;  // 994 .. 1006
-    if (__builtin_amdgcn_ballot_w64(unsure) != 0) return false;
+    const bool clear = rdy > 0.0f || ey - P.lo[1] >= top + 2;
+    if (__builtin_amdgcn_ballot_w64(unsure || !clear) != 0) return false;
     H.hit = 0; H.capped = 0; H.vx = H.vy = H.vz = 0; H.k = 0; H.sk = 0; H.steps = steps; H.iters = 0; H.work = 0; H.block_id = 0;
     H.t = -1.0f; H.hx = H.hy = H.hz = 0.0f;
     return true;

@@ -3,12 +3,13 @@
 //   k_terrain       : terrain_gen.comp:14-24 + noise.glsl:4-74 for a box of world voxels,
 //                     stored at their toroidal texels (bit-exact restatement: same
 //                     operation order as the shader, no FMA contraction).
-//   k_cell_masks    : one 64-bit occupancy mask per 4^3 cell of the texel image.
+//   k_cell_masks    : one 64-bit occupancy mask per 4^3 cell of the texel image, into the builders' plane of masks.
 //   k_df_x, k_df_y, k_df_z_pack : the separable (min, max) octant distance transform over cells (torus
 //                     metric), both directions of an axis per launch; the last packs the eight octant
-//                     distances of a cell into its 16-byte record.  All of these run on a box of cells.
-//   k_column_vtops, k_tops_reduce, k_voxel_pyramid : the column-top pyramid at voxel precision,
-//                     one 16-byte record per cell next to the cell records.
+//                     distances of a cell into the builders' plane of distances.  All of these run on a box of cells.
+//   k_column_vtops, k_tops_extend, k_tops_max, k_voxel_pyramid : column tops at voxel precision, their maxima over
+//                     squares of 1, 2, .. 256 cell columns, and the cells themselves: a 128-byte line per cell with the
+//                     record (mask, distances) and the eight box words of the traversal.
 //   k_any_nonzero   : is the uploaded distance image all zero (as shipped)?
 #include "vrt_device.h"
 #include "vrt_kernels.h"
@@ -100,6 +101,8 @@ VRT_DEV float snoise(float vx, float vy, float vz)
     return 42.0f * acc;
 }
 
+constexpr int NOISE_REACH = 32;  // no voxel further than this from y = 0 depends on the noise (k_terrain)
+
 // terrain_gen.comp:14-24 for world voxels [x0,x0+ex) x [y0,y0+ey) x [z0,z0+ez)
 template <typename T>
 __global__ __launch_bounds__(256) void k_terrain(T *block, int n, int x0, int y0, int z0, int ex, int ey, int ez)
@@ -109,13 +112,16 @@ __global__ __launch_bounds__(256) void k_terrain(T *block, int n, int x0, int y0
     const int lz = blockIdx.z;
     if (lx >= ex || ly >= ey || lz >= ez) return;
     const int px = x0 + lx, py = y0 + ly, pz = z0 + lz;
-    // |snoise| < 11 for every input: each of the four corner terms is at most
-    // 42 * max_r (0.6 - r^2)^4 * r * |gradient| = 42 * 0.0209 * |gradient|, and a gradient (components in
-    // [-1,1], scaled by taylorInvSqrt of a squared length <= 3) is shorter than 3.1.  So for |y| > 128 the
-    // sign of snoise*6 - y is the sign of -y whatever the noise is, and the 500-odd instructions of the
-    // noise are skipped (a wavefront shares y).  The CPU oracle evaluates the noise everywhere.
+    // |snoise| < 3.6 for every input.  Each of the four corner terms is 42 * m^4 * dot(p, x) with m = 0.6 - |x|^2 (or 0) and
+    // p the corner's gradient: at most 42 * max_r (0.6 - r^2)^4 * r * |p| = 42 * 0.02089 * |p| (the maximum lies at
+    // r^2 = 0.6 / 9).  A gradient lies on the octahedron |x| + |y| + |h| = 1 before it is scaled (noise.glsl:49-63 fold the
+    // points with h < 0 back onto it), so its squared length s lies in [1/3, 1], and scaled by taylorInvSqrt(s) =
+    // 1.79284 - 0.85373 s its length sqrt(s) * (1.79284 - 0.85373 s) is at most 1.0001 (the maximum lies at s = 0.70).  Four
+    // corners: 4 * 42 * 0.02089 * 1.0001 = 3.51, and rounding adds a few parts in a million.  So |snoise * 6| < 22, and
+    // for |y| > NOISE_REACH = 32 the sign of snoise*6 - y is the sign of -y whatever the noise is: the 500-odd instructions
+    // of the noise are skipped (a wavefront shares y).  The CPU oracle evaluates the noise everywhere.
     T v;
-    if (py > 128 || py < -128) {
+    if (py > NOISE_REACH || py < -NOISE_REACH) {
         v = py < 0 ? (T)1 : (T)0;
     } else {
         const float noise_val = snoise((float)px * 0.015f, (float)py * 0.015f, (float)pz * 0.015f) * 6.0f - (float)py;
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(256) void k_terrain_chunks(T *block, int n, ChunkBa
     const int py = c[1] * 32 + (int)(blockIdx.y * 8u + (threadIdx.x >> 5));
     const int pz = c[2] * 32 + (int)blockIdx.z;
     T v;
-    if (py > 128 || py < -128) {  // see k_terrain
+    if (py > NOISE_REACH || py < -NOISE_REACH) {  // see k_terrain
         v = py < 0 ? (T)1 : (T)0;
     } else {
         const float noise_val = snoise((float)px * 0.015f, (float)py * 0.015f, (float)pz * 0.015f) * 6.0f - (float)py;
@@ -179,8 +185,8 @@ hipError_t launch_terrain(void *block, int voxel_bytes, int n, int x0, int y0, i
 // ---------------------------------------------------------------------------
 // cell records: cell (cx,cy,cz) covers texels [4c, 4c+4)^3
 // ---------------------------------------------------------------------------
-// A cell's record and its column-top words lie in one 128-byte line: `cells` points at the record of cell 0 and cell
-// i's is cells[CELL_U4 * i]; the column-top kernel writes out[CELL_U4 * i .. + 3] with out = cells + 1.  A ray that
+// A cell's record and its box words lie in one 128-byte line: `cells` points at the record of cell 0 and cell
+// i's is cells[CELL_U4 * i], its box words behind it; k_voxel_pyramid writes both, from the builders' planes.  A ray that
 // lands in a cell reads the record and one of the words, and among rays that have little to do with each other that is
 // one miss in the L2 per cell instead of two.
 // Every builder below works on a box of cells of the torus: origin o (each coordinate in [0, nc)) and extent e
@@ -203,8 +209,8 @@ VRT_DEV bool box_cell(const CellBox &b, int nc, int &cx, int &cy, int &cz)
 static dim3 box_grid(const CellBox &b) { return dim3((b.ex + 63) / 64, (b.ey + 3) / 4, b.ez); }
 
 // occupancy mask, bit = z*16 + y*4 + x, into the builders' own plane of masks (8 bytes per cell, side by side: the
-// passes below read 32 masks ahead of every cell, which would be 32 lines of the 128-byte cells); k_df_z_pack writes a
-// cell's record, mask and distances, in one piece
+// passes below read 32 masks ahead of every cell, which would be 32 lines of the 128-byte cells); k_voxel_pyramid copies
+// it into the cell's record
 template <typename T>
 __global__ __launch_bounds__(256) void k_cell_masks(const T *block, int n, int nc, CellBox box, uint2 *masks)
 {
@@ -288,9 +294,10 @@ __global__ __launch_bounds__(256) void k_df_y(const uint8_t *tx, int nc, CellBox
     }
 }
 
-// the eight octant distances of a cell, byte o = sx | sy << 1 | sz << 2, into the record's .z and .w words, behind the
-// cell's mask
-__global__ __launch_bounds__(256) void k_df_z_pack(const uint8_t *ty, const uint2 *masks, int nc, CellBox box, uint4 *cells)
+// the eight octant distances of a cell, byte o = sx | sy << 1 | sz << 2: the record's .z and .w words, into the builders'
+// own plane of distances (side by side like the masks; k_voxel_pyramid, which every change of the index is followed by,
+// writes the cells themselves, a whole cell at a time)
+__global__ __launch_bounds__(256) void k_df_z_pack(const uint8_t *ty, int nc, CellBox box, uint2 *dists)
 {
     int cx, cy, cz;
     if (!box_cell(box, nc, cx, cy, cz)) return;
@@ -304,8 +311,7 @@ __global__ __launch_bounds__(256) void k_df_z_pack(const uint8_t *ty, const uint
         lo |= (unsigned)df_scan(value, self, cz, nc, -1) << (8 * sxy);
         hi |= (unsigned)df_scan(value, self, cz, nc, 1) << (8 * sxy);
     }
-    const uint2 m = masks[(size_t)cz * plane + base];
-    cells[CELL_U4 * ((size_t)cz * plane + base)] = make_uint4(m.x, m.y, lo, hi);
+    dists[(size_t)cz * plane + base] = make_uint2(lo, hi);
 }
 
 // box [lo, lo + len) of an axis widened by `grow` cells on both sides, on a torus of nc cells
@@ -324,9 +330,9 @@ hipError_t launch_update_cells(const void *block, int voxel_bytes, int n, uint4 
     if (b.ex <= 0 || b.ey <= 0 || b.ez <= 0) return hipSuccess;
     const size_t ncells = (size_t)nc * nc * nc;
     const dim3 blockdim(256);
-    // planes: the masks (8 bytes per cell), the two x planes, the four y planes
-    uint2   *masks = reinterpret_cast<uint2 *>(planes);
-    uint8_t *tx = planes + 8 * ncells, *ty = planes + 10 * ncells;
+    // planes: the masks and the octant distances (8 bytes per cell each), the two x planes, the four y planes
+    uint2   *masks = reinterpret_cast<uint2 *>(planes), *dists = masks + ncells;
+    uint8_t *tx = planes + 16 * ncells, *ty = planes + 18 * ncells;
     if (voxel_bytes == 1) k_cell_masks<uint8_t><<<box_grid(b), blockdim, 0, s>>>((const uint8_t *)block, n, nc, b, masks);
     else k_cell_masks<uint16_t><<<box_grid(b), blockdim, 0, s>>>((const uint16_t *)block, n, nc, b, masks);
     widen(b.ox, b.ex, DF_CAP - 1, nc);
@@ -334,7 +340,7 @@ hipError_t launch_update_cells(const void *block, int voxel_bytes, int n, uint4 
     widen(b.oy, b.ey, DF_CAP - 1, nc);
     k_df_y<<<box_grid(b), blockdim, 0, s>>>(tx, nc, b, ty);
     widen(b.oz, b.ez, DF_CAP - 1, nc);
-    k_df_z_pack<<<box_grid(b), blockdim, 0, s>>>(ty, masks, nc, b, cells);
+    k_df_z_pack<<<box_grid(b), blockdim, 0, s>>>(ty, nc, b, dists);
     return hipGetLastError();
 }
 
@@ -406,7 +412,7 @@ __global__ __launch_bounds__(256) void k_column_vtops(const uint2 *masks, int nc
 // The square is taken when twice its side exceeds the cube's (measured in the traversal, when it chose: better than once
 // and than four times).  One thread per cell and pair of words (a quadrant of travel, negative x | negative z << 1), the
 // four threads of a cell side by side: 64 bytes in a row.
-__global__ __launch_bounds__(256) void k_voxel_pyramid(int nc, int offcy, TopsLevels tl, uint4 *cells)
+__global__ __launch_bounds__(256) void k_voxel_pyramid(int nc, int offcy, TopsLevels tl, const uint2 *masks, const uint2 *dists, uint4 *cells)
 {
     const int tx = blockIdx.x * 256 + threadIdx.x;
     const int tcx = tx >> 2, q = tx & 3;
@@ -415,7 +421,8 @@ __global__ __launch_bounds__(256) void k_voxel_pyramid(int nc, int offcy, TopsLe
     if (tcx >= nc) return;
     int wl = tcy - offcy;
     wl += wl < 0 ? nc : 0;
-    uint4 *cell = cells + CELL_U4 * (((size_t)tcz * nc + tcy) * nc + tcx);
+    const size_t at = ((size_t)tcz * nc + tcy) * nc + tcx;
+    uint4 *cell = cells + CELL_U4 * at;
     // the square of level L that extends towards -x has its corner 2^L - 1 columns before the cell
     const bool negx = (q & 1) != 0, negz = (q & 2) != 0;
     // Any level whose square lies at or below the voxel gives a valid box; two choices are kept.
@@ -442,7 +449,7 @@ __global__ __launch_bounds__(256) void k_voxel_pyramid(int nc, int offcy, TopsLe
         }
     }
     // octant distances of the cell's record: byte o = sx | sy << 1 | sz << 2, bit set = positive direction
-    const uint2 dist = reinterpret_cast<const uint2 *>(cell)[1];
+    const uint2 dist = dists[at];
     const int   oxz = (negx ? 0 : 1) | (negz ? 0 : 4);
     const int   d_up = (int)(((oxz & 4 ? dist.y : dist.x) >> (8 * ((oxz | 2) & 3))) & 0xffu);
     const int   d_down = (int)(((oxz & 4 ? dist.y : dist.x) >> (8 * (oxz & 3))) & 0xffu);
@@ -458,6 +465,7 @@ __global__ __launch_bounds__(256) void k_voxel_pyramid(int nc, int offcy, TopsLe
                   : d_down > 0             ? ((unsigned)(d_down - 1) << 8) | (unsigned)(j + 4 * (d_down - 1))
                                            : BOX_NONE;
     }
+    if (q == 0) { const uint2 m = masks[at]; cell[0] = make_uint4(m.x, m.y, dist.x, dist.y); }  // the record
     cell[1 + q] = make_uint4(up[0] | (up[1] << 16), up[2] | (up[3] << 16), down[0] | (down[1] << 16), down[2] | (down[3] << 16));
 }
 
@@ -488,7 +496,8 @@ hipError_t launch_build_voxel_pyramid(const uint8_t *planes, int nc, int offcy, 
         level = coarse;
         tl.tops[L] = level; tl.levels = L;
     }
-    k_voxel_pyramid<<<dim3((4 * nc + 255) / 256, nc, nc), blockdim, 0, s>>>(nc, offcy, tl, cells);
+    const uint2 *masks = reinterpret_cast<const uint2 *>(planes);
+    k_voxel_pyramid<<<dim3((4 * nc + 255) / 256, nc, nc), blockdim, 0, s>>>(nc, offcy, tl, masks, masks + (size_t)nc * nc * nc, cells);
     return hipGetLastError();
 }
 

@@ -90,22 +90,19 @@ VRT_DEV int argmin3(float a, float b, float c)
     return idx;
 }
 
-// 1 / x for the direction components of an ordinary ray: the compiler's own division sequence (reciprocal
-// estimate, one Newton step, two quotient corrections, all fused multiply-adds) without the operand
-// scaling and the special-case fix-up around it.  Those only act on operands whose quotient is zero, denormal,
-// infinite or NaN, so for every x with |x| <= 2 and |1 / x| < 2^100 the result has the bits of 1.0f / x, and
-// for every other such x (and NaN) it is not below 2^100 in magnitude either -- which is all the traversal
-// asks (ray_is_regular; a component of a normalised direction never exceeds 1).  vrt_selftest_recip checks
-// both statements for every such argument.
+// 1 / x for the direction components of an ordinary ray: the hardware's reciprocal estimate and one Newton step on it,
+// two fused multiply-adds -- the head of the compiler's own division sequence, without the two quotient corrections
+// that follow it there and without the operand scaling and the special-case fix-up around it.  For every x with
+// |x| <= 2 and |1 / x| < 2^100 the result has the bits of 1.0f / x all the same (the corrections change nothing when the
+// numerator is 1, and the wrappers only act on operands whose quotient is zero, denormal, infinite or NaN), and for
+// every other such x (and NaN) it is not below 2^100 in magnitude either -- which is all the traversal asks
+// (ray_is_regular; a component of a normalised direction never exceeds 1).  vrt_selftest_recip checks both statements
+// for every such argument; tools/rcp_probe.hip counts, for each shorter and longer form, the arguments that differ.
 VRT_DEV float recip_regular(float x)
 {
-    float       r = __builtin_amdgcn_rcpf(x);
+    const float r = __builtin_amdgcn_rcpf(x);
     const float e = __builtin_fmaf(-x, r, 1.0f);
-    r = __builtin_fmaf(e, r, r);
-    float rem = __builtin_fmaf(-x, r, 1.0f);
-    float q   = __builtin_fmaf(rem, r, r);
-    rem = __builtin_fmaf(-x, q, 1.0f);
-    return __builtin_fmaf(rem, r, q);
+    return __builtin_fmaf(e, r, r);
 }
 
 // sqrtf(x) and a / b for operands far from the edges of the float range, as ray generation has them for every

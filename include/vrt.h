@@ -83,7 +83,8 @@ typedef struct vrt_outputs {
  * pixel): VRT_TILE_LOG2H=k (wavefront tile of (64 >> k) x (1 << k) pixels instead of 32 x 2), VRT_NO_ROW_ORDER=1
  * (workgroup rows always top to bottom), VRT_ROW_BLOCK0=r (always start at workgroup row r), VRT_SCHED_DEBUG=1
  * (print what each launch measured; synchronises), VRT_SECONDARY=pixel (vrt_trace_secondary without the LDS
- * binning), VRT_NO_SKY=1 (wavefronts whose rays can only meet air are traced like any other); vrt_comm_create reads VRT_COMM_SELF_SENDRECV=1 (the root's own part through RCCL as well). */
+ * binning), VRT_NO_SKY=1 (wavefronts whose rays can only meet air are traced like any other), VRT_SKY_REACH=f (how steeply a ray
+ * may descend and still be tried for that short cut); vrt_comm_create reads VRT_COMM_SELF_SENDRECV=1 (the root's own part through RCCL as well). */
 /* ≙ GraphicsCore::new (src/graphics/mod.rs:292-425), minus window/swapchain:
  * picks the device, creates the stream, allocates the N^3 world images. */
 int vrt_create(const vrt_config *cfg, vrt_ctx **out);

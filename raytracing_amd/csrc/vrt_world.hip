@@ -131,6 +131,31 @@ __global__ __launch_bounds__(256) void k_terrain(T *block, int n, int x0, int y0
     block[(tz * (size_t)n + ty) * (size_t)n + tx] = v;
 }
 
+// The same for byte voxels, four along x per thread and one 32-bit store (x0 and ex multiples of 4, as a window's are):
+// far from y = 0, where no noise is evaluated, the kernel is its stores, and a wavefront's 64 single bytes fill half a
+// cache line where 64 words fill two.
+__global__ __launch_bounds__(256) void k_terrain_u8x4(uint8_t *block, int n, int x0, int y0, int z0, int ex4, int ey, int ez)
+{
+    const int lx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ly = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int lz = blockIdx.z;
+    if (lx >= ex4 || ly >= ey || lz >= ez) return;
+    const int px = x0 + 4 * lx, py = y0 + ly, pz = z0 + lz;
+    unsigned v = 0;
+    if (py > NOISE_REACH || py < -NOISE_REACH) {  // see k_terrain
+        v = py < 0 ? 0x01010101u : 0u;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float noise_val = snoise((float)(px + i) * 0.015f, (float)py * 0.015f, (float)pz * 0.015f) * 6.0f - (float)py;
+            v |= (noise_val > 0.0f ? 1u : 0u) << (8 * i);
+        }
+    }
+    // (px is a multiple of 4 and so is n: the four texels do not wrap apart)
+    const size_t tx = (size_t)rem_euclid(px, n), ty = (size_t)rem_euclid(py, n), tz = (size_t)rem_euclid(pz, n);
+    *reinterpret_cast<uint32_t *>(block + (tz * (size_t)n + ty) * (size_t)n + tx) = v;
+}
+
 // the same for up to 64 chunks of 32^3 voxels per launch (positions in chunk units): a workgroup is 32 x 8 voxels
 // of one chunk, so every lane of a wavefront has a voxel
 struct ChunkBatch {
@@ -177,7 +202,9 @@ hipError_t launch_terrain(void *block, int voxel_bytes, int n, int x0, int y0, i
     if (ex <= 0 || ey <= 0 || ez <= 0) return hipSuccess;
     // grid.z is limited to 65535; ez <= 4096 here.
     const dim3 grid((ex + 63) / 64, (ey + 3) / 4, ez), blockdim(256);
-    if (voxel_bytes == 1) k_terrain<uint8_t><<<grid, blockdim, 0, s>>>((uint8_t *)block, n, x0, y0, z0, ex, ey, ez);
+    if (voxel_bytes == 1 && (x0 & 3) == 0 && (ex & 3) == 0 && (n & 3) == 0)
+        k_terrain_u8x4<<<dim3((ex / 4 + 63) / 64, (ey + 3) / 4, ez), blockdim, 0, s>>>((uint8_t *)block, n, x0, y0, z0, ex / 4, ey, ez);
+    else if (voxel_bytes == 1) k_terrain<uint8_t><<<grid, blockdim, 0, s>>>((uint8_t *)block, n, x0, y0, z0, ex, ey, ez);
     else k_terrain<uint16_t><<<grid, blockdim, 0, s>>>((uint16_t *)block, n, x0, y0, z0, ex, ey, ez);
     return hipGetLastError();
 }

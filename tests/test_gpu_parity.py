@@ -314,6 +314,36 @@ def test_frame_only_launches_over_sky_match_the_oracle():
         assert both  # (some pose sees both colours of sky)
 
 
+def test_sky_short_cut_changes_no_pixel_of_the_full_size_frame(monkeypatch):
+    """Frame-only launches at 1080p over the 1024^3 terrain, two contexts on one world: one takes the short cut for
+    wavefronts of sky, one (VRT_NO_SKY=1) traces every ray; cameras from under the surface to 400 voxels above it, looking
+    down, along the horizon and up.  Every pixel equal, with both pixel formats."""
+    import torch
+    n, w, h = 1024, 1920, 1080
+    base = scenes.pose_headline()
+    wmin = scenes.window_min(base.get_position(), n)
+    rng = np.random.default_rng(5)
+    with GraphicsCore(grid_n=n, voxel_format=VOXEL_PACKED_U8, trace_mode=TRACE_SKIP) as a:
+        monkeypatch.setenv("VRT_NO_SKY", "1")
+        with GraphicsCore(grid_n=n, voxel_format=VOXEL_PACKED_U8, trace_mode=TRACE_SKIP) as b:
+            monkeypatch.delenv("VRT_NO_SKY")
+            for g in (a, b):
+                g.generate_window(wmin)
+                g.reset_distance_field()
+            fa, fb = (torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda") for _ in range(2))
+            ta, tb = (torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda") for _ in range(2))
+            chunk = np.array(scenes.chunk_of(base.get_position()), np.float32) * 32
+            for i in range(24):
+                pos = (chunk + rng.uniform(0.01, 31.99, 3)).astype(np.float32)
+                pos[1] = np.float32([-3.0, 7.5, 9.0, 40.3, 120.0, 400.0][i % 6] + rng.uniform(0.0, 1.0))
+                cam = scenes.cam16(Player.at(pos, float(rng.uniform(-3.2, 3.2)), float([-0.9, -0.05, 0.0, 0.03, 0.4, 1.3][(i // 6 + i) % 6])))
+                a.trace_device(cam, w, h, 0, h, {"bgra8": fa.data_ptr(), "bgr8": ta.data_ptr()})
+                b.trace_device(cam, w, h, 0, h, {"bgra8": fb.data_ptr(), "bgr8": tb.data_ptr()})
+                a.sync(); b.sync()
+                assert torch.equal(fa, fb), (i, pos.tolist())
+                assert torch.equal(ta, tb), (i, pos.tolist())
+
+
 def test_nonzero_distance_image_takes_the_literal_kernel():
     rng = np.random.default_rng(11)
     n = 64
